@@ -1,0 +1,131 @@
+"""Import the *real* reference (kkoutini/PaSST at /root/reference) on CPU (TEST INFRASTRUCTURE).
+
+Only usable in the build container: /root/reference does not exist on the GPU box, so this
+module is imported solely by ``tests/golden/make_golden.py`` (fixture generation) and by the
+``-m "not gpu"`` pinning tests, which skip when the tree is absent.
+
+The reference needs third-party packages that are not installed here (timm, ba3l/sacred,
+torchaudio).  We stub exactly the symbols it touches:
+
+* ``timm.models._hub.download_cached_file``  (models/helpers/vit_helpers.py:13-16)
+* ``ba3l.ingredients.ingredient.Ingredient`` (models/passt.py:915-922, models/preprocess.py:8-18)
+* ``torchaudio.compliance.kaldi.get_mel_banks`` and ``torchaudio.transforms.{Frequency,Time}Masking``
+  (models/preprocess.py:50,54,71-72) -- torchaudio 0.13.1 is an un-vendored dependency
+  (environment.yml:99); its published algorithm is restated in ``oracle/passt_oracle.py``
+  and injected here, so the reference's own ``AugmentMelSTFT.forward`` runs end to end.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "models", "passt.py"))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_loaded = {}
+
+
+def load_reference():
+    """Returns (ref_passt_module, ref_preprocess_module)."""
+    if _loaded:
+        return _loaded["passt"], _loaded["pre"]
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+    import torch
+    from . import passt_oracle as O
+
+    _mod("timm")
+    _mod("timm.models")
+    _mod("timm.models._hub", download_cached_file=lambda *a, **k: None)
+
+    class Ingredient:
+        def __init__(self, path):
+            self.path = path
+
+        def add_config(self, **kw):
+            pass
+
+        def command(self, f=None, **kw):
+            return f
+
+    _mod("ba3l")
+    _mod("ba3l.ingredients")
+    _mod("ba3l.ingredients.ingredient", Ingredient=Ingredient)
+
+    class _AxisMasking(torch.nn.Module):
+        def __init__(self, mask_param, axis, iid_masks):
+            super().__init__()
+            self.mask_param, self.axis, self.iid_masks = mask_param, axis, iid_masks
+
+        def forward(self, specgram, mask_value=0.0):
+            # torchaudio 0.13.1 _AxisMasking.forward: iid variant only for 4-D input.
+            assert not (self.iid_masks and specgram.dim() == 4)
+            return O.mask_along_axis(specgram, self.mask_param, mask_value, self.axis)
+
+    class FrequencyMasking(_AxisMasking):
+        def __init__(self, freq_mask_param, iid_masks=False):
+            super().__init__(freq_mask_param, 1, iid_masks)
+
+    class TimeMasking(_AxisMasking):
+        def __init__(self, time_mask_param, iid_masks=False, p=1.0):
+            super().__init__(time_mask_param, 2, iid_masks)
+
+    ta = _mod("torchaudio")
+    ta.compliance = _mod("torchaudio.compliance")
+    ta.compliance.kaldi = _mod("torchaudio.compliance.kaldi", get_mel_banks=O.kaldi_get_mel_banks)
+    ta.transforms = _mod("torchaudio.transforms", FrequencyMasking=FrequencyMasking,
+                         TimeMasking=TimeMasking)
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    saved = sys.modules.pop("models", None), sys.modules.pop("models.passt", None), \
+        sys.modules.pop("models.preprocess", None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import importlib
+        ref_passt = importlib.import_module("models.passt")
+        ref_pre = importlib.import_module("models.preprocess")
+    # keep the reference modules under private names and restore whatever 'models' was
+    for k in ("models", "models.passt", "models.preprocess", "models.helpers",
+              "models.helpers.vit_helpers"):
+        m = sys.modules.pop(k, None)
+        if m is not None:
+            sys.modules["_ref_" + k] = m
+    for k, m in zip(("models", "models.passt", "models.preprocess"), saved):
+        if m is not None:
+            sys.modules[k] = m
+    sys.path.remove(REFERENCE_ROOT)
+    _loaded["passt"], _loaded["pre"] = ref_passt, ref_pre
+    return ref_passt, ref_pre
+
+
+def build_reference_passt(cfg: dict, state_dict: dict):
+    """Instantiate the reference ``PaSST`` class (models/passt.py:383) with ``cfg`` and load
+    ``state_dict`` (numpy arrays) into it.  stdout chatter (first_RUN prints) is silenced."""
+    import torch
+    ref_passt, _ = load_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref_passt.PaSST(
+            u_patchout=cfg.get("u_patchout", 0), s_patchout_t=cfg.get("s_patchout_t", 0),
+            s_patchout_f=cfg.get("s_patchout_f", 0), img_size=tuple(cfg["img_size"]),
+            patch_size=cfg.get("patch", 16), stride=tuple(cfg["stride"]), in_chans=1,
+            num_classes=cfg["num_classes"], embed_dim=cfg["embed_dim"], depth=cfg["depth"],
+            num_heads=cfg["num_heads"], distilled=True)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state_dict.items()}, strict=True)
+    return m
+
+
+def run_silently(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)

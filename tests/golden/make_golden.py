@@ -1,0 +1,145 @@
+"""Generate the golden fixtures in this directory by running the REAL reference
+(kkoutini/PaSST, imported read-only from /root/reference through oracle/ref_import.py).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Only outputs are stored; inputs/weights are regenerated bit-exactly by oracle/detgen.py.
+The GPU box has no /root/reference -- the `-m gpu` parity tests compare the HIP path with
+these committed files (and with the oracle, itself pinned to these files by the CPU suite).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import detgen, ref_import  # noqa: E402
+from oracle import passt_oracle as O   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# ---- shared case definitions (imported by the tests too) ---------------------------------
+SMALL = dict(embed_dim=128, depth=2, num_heads=2, num_classes=37, img_size=(128, 250),
+             stride=(10, 10))
+CASES = {
+    # conv grid is 12x24 but the embedding grid is 12x25 -> exercises the time-pos-embed crop
+    "model_small_eval": dict(cfg=O.make_cfg(**SMALL), B=2, T=250, training=False, seed=11),
+    "model_small_train": dict(cfg=O.make_cfg(**SMALL, s_patchout_t=6, s_patchout_f=3, u_patchout=5),
+                              B=3, T=250, training=True, seed=12, torch_seed=1234),
+    # structured patchout only, 3 heads, stride 16 grid
+    "model_s16_train": dict(cfg=O.make_cfg(embed_dim=192, depth=1, num_heads=3, num_classes=50,
+                                           img_size=(128, 320), stride=(16, 16),
+                                           s_patchout_t=5, s_patchout_f=2),
+                            B=2, T=320, training=True, seed=13, torch_seed=77),
+    # BASELINE config #1 at full width/depth: passt_s_swa_p16_128_ap476, eval, no patchout
+    "model_passt_s_eval": dict(cfg=O.make_cfg(), B=1, T=998, training=False, seed=14),
+}
+FRONTEND_CASES = {
+    "frontend_eval": dict(B=2, L=32000, training=False, seed=21,
+                          kw=dict(fmin_aug_range=10, fmax_aug_range=2000)),
+    "frontend_eval_10s": dict(B=1, L=320000, training=False, seed=22,
+                              kw=dict(fmin_aug_range=10, fmax_aug_range=2000)),
+    "frontend_train": dict(B=2, L=48000, training=True, seed=23, torch_seed=99,
+                           kw=dict(fmin_aug_range=10, fmax_aug_range=2000, freqm=48, timem=40)),
+    "frontend_esc50": dict(B=2, L=16000, training=False, seed=24,
+                           kw=dict(fmin_aug_range=10, fmax_aug_range=2000, freqm=48, timem=80)),
+}
+
+
+def model_inputs(case):
+    cfg, B, T = case["cfg"], case["B"], case["T"]
+    x = detgen.uniform(case["seed"], "x", (B, 1, cfg["img_size"][0], T), -1.5, 1.5)
+    y = (detgen.uniform(case["seed"], "y", (B, cfg["num_classes"]), 0.0, 1.0) < 0.1).astype(np.float32)
+    return x, y
+
+
+def frontend_inputs(case):
+    w = detgen.uniform(case["seed"], "wave", (case["B"], case["L"]), -1.0, 1.0)
+    # a little structure so the spectrum is not flat: amplitude-modulated noise + a chirp
+    n = np.arange(case["L"], dtype=np.float64)
+    chirp = 0.3 * np.sin(2 * np.pi * (200.0 + 0.05 * n) * n / 32000.0)
+    return (0.1 * w * (1.0 + 0.5 * np.sin(n / 977.0)) + chirp).astype(np.float32)
+
+
+def subsample(g):
+    """Full tensor for small ones; every 7th element + L2 norm for large ones."""
+    flat = np.ascontiguousarray(g).reshape(-1)
+    if flat.size <= 4096:
+        return flat.copy(), float(np.linalg.norm(flat.astype(np.float64)))
+    return flat[::7].copy(), float(np.linalg.norm(flat.astype(np.float64)))
+
+
+def gen_model_case(name, case):
+    cfg = case["cfg"]
+    sd = detgen.passt_state_dict(cfg, case["seed"])
+    x, y = model_inputs(case)
+    m = ref_import.build_reference_passt(cfg, sd)
+    m.train(case["training"])
+    out = {}
+    if case["training"]:
+        torch.manual_seed(case["torch_seed"])
+        logits, feat = ref_import.run_silently(m, torch.from_numpy(x))
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(
+            logits, torch.from_numpy(y), reduction="none").mean()          # ex_audioset.py:184-186
+        loss.backward()
+        out["loss"] = np.float32(loss.item())
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                out["gradnone." + k] = np.zeros(0, np.float32)
+            else:
+                s, nrm = subsample(p.grad.numpy())
+                out["grad." + k] = s
+                out["gradnorm." + k] = np.float64(nrm)
+        # replay the index draws (same seed, same call order) so the fixture holds them
+        torch.manual_seed(case["torch_seed"])
+        Fd = (cfg["img_size"][0] - cfg["patch"]) // cfg["stride"][0] + 1
+        Td = (case["T"] - cfg["patch"]) // cfg["stride"][1] + 1
+        d = O.draw_patchout(cfg, Fd, Td, True)
+        out["toff"] = np.int64(d["toff"])
+        for k in ("idx_t", "idx_f", "idx_u"):
+            out[k] = d[k].numpy() if d[k] is not None else np.zeros(0, np.int64)
+    else:
+        with torch.no_grad():
+            logits, feat = ref_import.run_silently(m, torch.from_numpy(x))
+    out["logits"] = logits.detach().numpy()
+    out["features"] = feat.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "logits", out["logits"].shape, "absmax", float(np.abs(out["logits"]).max()))
+
+
+def gen_frontend_case(name, case):
+    _, ref_pre = ref_import.load_reference()
+    wave = frontend_inputs(case)
+    mel = ref_import.run_silently(ref_pre.AugmentMelSTFT, **case["kw"])
+    mel.train(case["training"])
+    if "torch_seed" in case:
+        torch.manual_seed(case["torch_seed"])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            out = mel(torch.from_numpy(wave))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), mel=out.numpy())
+    print(name, tuple(out.shape), "range", float(out.min()), float(out.max()))
+
+
+def gen_rng_kat():
+    """SURVEY.md App. C KAT: the index path on torch CPU."""
+    torch.manual_seed(123)
+    a = torch.randperm(99)[:59].sort().values.numpy()
+    b = torch.randperm(12)[:8].sort().values.numpy()
+    c = torch.randperm(472)[:72].sort().values.numpy()
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), t=a, f=b, u=c)
+
+
+if __name__ == "__main__":
+    assert ref_import.reference_available(), "needs /root/reference"
+    torch.set_num_threads(os.cpu_count())
+    for n, c in CASES.items():
+        gen_model_case(n, c)
+    for n, c in FRONTEND_CASES.items():
+        gen_frontend_case(n, c)
+    gen_rng_kat()
