@@ -1,0 +1,231 @@
+/* passt_amd.h -- C ABI of libpasst_amd.so, the MI355X (gfx950) implementation of the
+ * kkoutini/PaSST training hot path.
+ *
+ * The reference has no FFI of its own: its hot path is a chain of ATen / torchaudio calls inside
+ * two nn.Modules (models/preprocess.py:19 AugmentMelSTFT, models/passt.py:383 PaSST).  This
+ * header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md); each entry
+ * point names the reference call sites (file:line under the reference root) it replaces.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers, ints, floats; no torch types.
+ *   - the CALLER allocates every output and workspace; the library never allocates or frees
+ *     device memory and keeps no pointer after return.
+ *   - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises the device.  Re-entrant: no mutable global state.
+ *   - return value: 0 on success, a negative PA_E* code otherwise (never throws);
+ *     pa_error_string(code) describes it.
+ *   - `dtype` selects the storage/compute type of the "low precision" activations and GEMM
+ *     operands: PA_F32 (exact-f32 MFMA, the <=1e-3 parity mode) or PA_BF16 (bf16 MFMA with f32
+ *     accumulation, the throughput mode).  The residual stream, LayerNorm statistics, softmax,
+ *     master weights and all weight gradients are always f32.
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef PASST_AMD_H
+#define PASST_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+enum { PA_F32 = 0, PA_BF16 = 1 };
+
+enum {
+    PA_OK = 0,
+    PA_EINVAL = -1,   /* bad argument (null pointer, negative size, ...) */
+    PA_EUNSUPPORTED = -2, /* shape/dtype outside what the kernels cover */
+    PA_ELAUNCH = -3   /* hipLaunch failed; see pa_last_hip_error() */
+};
+
+int pa_abi_version(void);
+const char* pa_error_string(int code);
+/* hipGetLastError() of the calling thread as text (valid until the next call). */
+const char* pa_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Front end: AugmentMelSTFT.forward, models/preprocess.py:57-86 (K1..K8 in SURVEY.md 2.3)
+ * pre-emphasis (:59) -> STFT 1024/hop/hann(win) reflect-centred (:60-61) -> power (:62) ->
+ * kaldi mel filterbank as a sparse band product (:71-76) -> log(x+eps) (:78) -> SpecAugment
+ * frequency/time mask (:80-82) -> (x+4.5)/5 (:84), fused in one kernel.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_fft;        /* must be 1024 */
+    int32_t hop;          /* 320 */
+    int32_t n_mels;       /* <= 128 */
+    int32_t n_frames;     /* T = 1 + (L-1-1+... ) see pa_mel_num_frames */
+    float preemph;        /* 0.97: y[n] = x[n+1] - preemph*x[n]  (:46,:59) */
+    float mel_low;        /* mel(fmin) = 1127 ln(1+fmin/700) */
+    float inv_mel_delta;  /* (n_mels+1) / (mel(fmax) - mel(fmin)) */
+    float log_eps;        /* 1e-5 (:78) */
+    float out_add;        /* 4.5  (:84) */
+    float out_scale;      /* 0.2  (:84) */
+    int32_t fmask_start, fmask_end;   /* [start,end) mel rows forced to (0+out_add)*out_scale; empty if start>=end */
+    int32_t tmask_start, tmask_end;   /* same along time */
+} pa_mel_params;
+
+/* frames produced for a waveform of L samples: 1 + (L-1)/hop  (pre-emphasis shortens by one) */
+int pa_mel_num_frames(int L, int hop);
+/* wave[B][L] f32 -> out[B][n_mels][n_frames] f32.
+ * window[n_fft]  : analysis window already zero-padded/centred to n_fft (:38-40 + torch.stft rule)
+ * bin_mel[n_fft/2]: mel value of FFT bin k, 1127 ln(1 + k*sr/n_fft/700) (kaldi.get_mel_banks)
+ * twiddle[n_fft/2][2]: (cos, -sin)(2 pi k / n_fft), k = 0..n_fft/2-1 */
+int pa_mel_frontend_fwd(const float* wave, int B, int L, const float* window, const float* bin_mel,
+                        const float* twiddle, float* out, const pa_mel_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameter staging (no reference counterpart: AMP autocast casts weights per op)
+ * ------------------------------------------------------------------------------------------ */
+/* out[i] = (dtype) in[i] */
+int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, void* stream);
+/* in[R][C] (ld = ldi) of dtype in_dtype -> out[C][ldo] of dtype out_dtype, out[c][r] = in[r][c];
+ * columns r in [R, ldo) of out are zero-filled (K-padding for the weight-gradient GEMM). */
+int pa_transpose(const void* in, int in_dtype, int R, int C, int ldi, void* out, int out_dtype,
+                 int ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm: nn.LayerNorm in Block (models/passt.py:369,373,378-379; eps 1e-6 :426), final norm
+ * (:450,:570) and head.0 (:463, eps 1e-5).  K15 in SURVEY.md.
+ * ------------------------------------------------------------------------------------------ */
+/* x[M][D] f32 -> y[M][D] (dtype), mean[M], rstd[M] f32 (saved for backward; may be NULL). */
+int pa_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int dtype,
+                     float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* dx[M][D] = (dres ? dres : 0) + LN'(dy); optional dx_lp (dtype) copy of dx for the next GEMM.
+ * dgamma/dbeta[D] are OVERWRITTEN (or accumulated when accumulate != 0).
+ * ws: f32 workspace of pa_layernorm_bwd_ws_floats(M, D) elements. */
+int64_t pa_layernorm_bwd_ws_floats(int M, int D);
+int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gamma,
+                     const float* mean, const float* rstd, const float* dres, float* dx,
+                     void* dx_lp, float* dgamma, float* dbeta, int accumulate, float* ws, int M,
+                     int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[M][N] = A[M][K] * B[N][K]^T  (both operands K-contiguous), MFMA, f32 accumulation.
+ * Replaces every nn.Linear of the path: qkv (models/passt.py:345), proj (:359), fc1+GELU
+ * (:285-286), fc2 (:288), the patch-embed conv as an im2col GEMM (:323) and, with transposed
+ * operands, all their input/weight gradients (autograd mm / addmm backward; K26).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    PA_EPI_STORE = 0,      /* out_lp = acc + bias                                   */
+    PA_EPI_GELU = 1,       /* out_lp = acc + bias ; out_lp2 = gelu_erf(out_lp)      */
+    PA_EPI_RESID = 2,      /* out_f32[orow] = acc + bias + resid[rrow]  (f32 residual stream) */
+    PA_EPI_DGELU = 3,      /* out_lp = acc * gelu_erf'(aux)                         */
+    PA_EPI_PARTIAL = 4     /* split-K: out_f32[z][M][N] = partial sums (no bias)    */
+};
+typedef struct {
+    int32_t dtype;         /* PA_F32 / PA_BF16: type of A, B, aux, out_lp, out_lp2 */
+    int32_t epilogue;
+    int32_t M, N, K;       /* K*sizeof(dtype) must be a multiple of 128 bytes */
+    int32_t lda, ldb;
+    const void* A;
+    const void* B;
+    const float* bias;     /* [N] or NULL */
+    const float* resid;    /* PA_EPI_RESID: f32 [*][ldr] */
+    int32_t ldr;
+    /* PA_EPI_RESID row remap (patch-embed writes token rows and adds a per-patch table):
+     * if row_mod > 0: rrow = m % row_mod, orow = (m / row_mod) * out_batch_rows + out_row_off + m % row_mod
+     * else rrow = orow = m. */
+    int32_t row_mod, out_batch_rows, out_row_off;
+    const void* aux;       /* PA_EPI_DGELU: pre-activation [M][ldaux] (dtype) */
+    int32_t ldaux;
+    float* out_f32;        /* PA_EPI_RESID / PA_EPI_PARTIAL */
+    int32_t ldo32;
+    void* out_lp;
+    int32_t ldolp;
+    void* out_lp2;
+    int32_t ldolp2;
+    int32_t split_k;       /* PA_EPI_PARTIAL: number of K slices (grid.z); else must be 1 */
+} pa_gemm_args;
+int pa_gemm_nt(const pa_gemm_args* a, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_z partial[z][i], i < n */
+int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out, int accumulate,
+                       void* stream);
+/* out[r] = (accumulate ? out[r] : 0) + sum_c in[r][c], c < C  (bias gradients from dY^T) */
+int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate,
+              void* stream);
+/* out[c] = (accumulate ? out[c] : 0) + sum_r in[r][c]  -- f32 in, small R (head/LN partials) */
+int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention: Attention.forward, models/passt.py:343-361 minus the two Linears (K17-K19):
+ * softmax((Q K^T) * scale) V per (batch, head), flash-style (scores never reach HBM), head_dim 64.
+ * q/k/v are read in place from the qkv GEMM output [B*N][3*H*64] ([q|k|v] x head x 64, the
+ * reshape of :345); o is written token-major [B*N][H*64] (the transpose+reshape of :358).
+ * ------------------------------------------------------------------------------------------ */
+int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+                     float scale, int dtype, void* stream);
+/* dqkv[B*N][3*H*64] from do[B*N][H*64]; lse from the forward; delta: f32 workspace [B*H*N]. */
+int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
+                     const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N,
+                     float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch embedding + positional terms + Patchout: PatchEmbed.forward (models/passt.py:318-328) and
+ * PaSST.forward_features :508-564 (K10-K14).  Gather-first: only the patches that survive
+ * structured/unstructured Patchout are embedded.
+ * ------------------------------------------------------------------------------------------ */
+/* im2col of the kept patches: x[B][1][F][T] f32 -> cols[B*Np][P*P] (dtype).
+ * patch_f[Np], patch_t[Np]: grid coordinates (frequency row, time column) of kept patch p. */
+int pa_patch_gather(const float* x, int B, int F, int T, const int32_t* patch_f,
+                    const int32_t* patch_t, int Np, int P, int fstride, int tstride, void* cols,
+                    int dtype, void* stream);
+/* table[p][D] = bias + time_pos[:, toff + patch_t[p]] + freq_pos[:, patch_f[p]]   (f32)
+ * time_pos is [D][Tpe], freq_pos is [D][Fpe] (the reference's (1,D,1,Tpe)/(1,D,Fpe,1) params).
+ * Also writes the two prefix tokens: tok[b][0] = cls + npe[0], tok[b][1] = dist + npe[1]. */
+int pa_patch_pos_table(const float* bias, const float* time_pos, int Tpe, const float* freq_pos,
+                       int Fpe, const int32_t* patch_f, const int32_t* patch_t, int Np, int toff,
+                       int D, float* table, const float* cls, const float* dist, const float* npe,
+                       float* tok, int B, int Ntok, void* stream);
+/* backward of the above given dtok[B][Ntok][D] f32: gsum[Ntok][D] = sum_b dtok (ws), then
+ * d_cls, d_dist, d_npe[2][D], d_bias[D], d_time_pos[D][Tpe], d_freq_pos[D][Fpe] (all overwritten
+ * or accumulated), and dcols_src: the patch rows of dtok compacted to [B*Np][D] (dtype) for the
+ * weight-gradient GEMM. */
+int pa_patch_bwd(const float* dtok, int B, int Ntok, int D, const int32_t* patch_f,
+                 const int32_t* patch_t, int Np, int toff, int Tpe, int Fpe, float* gsum,
+                 float* d_cls, float* d_dist, float* d_npe, float* d_bias, float* d_time_pos,
+                 float* d_freq_pos, int accumulate, void* dpatch, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head: final norm on the two prefix tokens, their mean, head LayerNorm + Linear
+ * (models/passt.py:570-574, 583-585, 463-464; K23-K24) and the BCE loss of the caller
+ * (ex_audioset.py:184-186; K25).
+ * ------------------------------------------------------------------------------------------ */
+/* x[B][Ntok][D] f32 (last block output). feat[B][D], hn[B][D] (LN_1e-5(feat)), and saved
+ * statistics stats[B][6] = (mean0, rstd0, mean1, rstd1, meanh, rstdh). */
+int pa_head_pre_fwd(const float* x, int B, int Ntok, int D, const float* norm_g,
+                    const float* norm_b, float eps_norm, const float* hg, const float* hb,
+                    float eps_head, float* feat, float* hn, float* stats, void* stream);
+/* logits[B][C] = hn[B][D] W[C][D]^T + b  (small f32 GEMM, any C) */
+int pa_linear_f32_fwd(const float* x, const float* W, const float* b, float* y, int B, int C, int D,
+                      void* stream);
+/* dx[B][D] = dy[B][C] W[C][D]; dW[C][D] (+)= dy^T x; db[C] (+)= colsum(dy) */
+int pa_linear_f32_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW,
+                      float* db, int accumulate, int B, int C, int D, void* stream);
+/* backward of pa_head_pre_fwd: dhn[B][D] (+ optional dfeat[B][D]) -> dx[B][Ntok][D] (rows 0,1
+ * written, all other rows ZEROED), and per-batch partials part[B][4][D] =
+ * (d_hg, d_hb, d_norm_g, d_norm_b) to be column-summed by the caller with pa_colsum_f32. */
+int pa_head_pre_bwd(const float* dhn, const float* dfeat, const float* x, const float* feat, int B,
+                    int Ntok, int D, const float* norm_g, const float* hg, const float* stats, float* dx,
+                    float* part, void* stream);
+/* loss[0] = mean BCE-with-logits; dlogits = grad_scale * d loss / d logits.  ws: >= 1 + ceil(B*C/256) floats */
+int pa_bce_fwd_bwd(const float* logits, const float* target, int B, int C, float grad_scale,
+                   float* loss, float* dlogits, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-step glue of the caller ("next" rows)
+ * ------------------------------------------------------------------------------------------ */
+/* ex_audioset.py:175-177 / helpers/mixup.py: out[b] = x[b]*lam[b] + x[perm[b]]*(1-lam[b]) */
+int pa_mixup(const float* x, const int32_t* perm, const float* lam, float* out, int B,
+             int64_t per_sample, void* stream);
+/* torch.optim.AdamW (ex_audioset.py:104-109) on one flat f32 parameter buffer */
+int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, void* stream);
+/* torch.optim.SGD lr only (ex_audioset.py:392 model_speed_test) */
+int pa_sgd(float* p, const float* g, int64_t n, float lr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASST_AMD_H */

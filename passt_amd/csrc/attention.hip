@@ -1,0 +1,433 @@
+// Fused (flash-style) multi-head attention, head_dim 64, forward and backward, for gfx950.
+// Reference: Attention.forward, models/passt.py:343-361 without the two Linears:
+//   attn = softmax((q @ k^T) * scale) ; x = attn @ v          (:348-358)
+// The N x N score matrix never reaches HBM (the reference materialises B*H*N*N*4 bytes per layer).
+//
+// Work decomposition: one 256-thread workgroup = 4 waves x 32 rows of the "owned" sequence axis
+// (queries for fwd / dQ, keys for dK,dV); the other axis streams through LDS in tiles of 64 rows.
+// All products use 32x32 MFMA tiles in the *transposed* orientation, so the owned row index is the
+// lane (lane&31) and softmax statistics are lane-local; the streamed index runs over accumulator
+// registers.  P (or dS) feeds the second product directly from those registers (acc_frag), the
+// matching operand is read down LDS columns (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32).
+//
+// q/k/v are read in place from the qkv GEMM output [B*N][3*H*64]; o / dqkv are token-major.
+#include <algorithm>
+
+#include "pa_mma.h"
+
+namespace pa {
+
+static constexpr int HD = 64;       // head dim (all PaSST archs: 768/12, 1024/16, 384/6, 128/2)
+static constexpr int TROWS = 64;    // streamed rows per LDS tile
+static constexpr float LOG2E = 1.4426950408889634f;
+static constexpr float LN2 = 0.6931471805599453f;
+
+template <typename T> struct Tile {
+    static constexpr int RB = HD * (int)sizeof(T);            // row bytes: 128 (bf16) / 256 (f32)
+    static constexpr int CPR = RB / 16;                        // 16-byte chunks per row
+    static constexpr int BYTES = TROWS * RB;                   // 8 KiB / 16 KiB
+    static constexpr int EPC = 16 / (int)sizeof(T);            // elements per chunk
+    static constexpr int NFRAG = RB / 32;                      // row fragments per row: 4 / 8
+};
+
+// global [rows][ld] (row index clamped to nrows-1) -> swizzled LDS tile, all 256 threads
+template <typename T>
+__device__ __forceinline__ void load_tile(char* lds, const T* g, int64_t ld, int row0, int nrows, int tid) {
+    constexpr int PER = TROWS * Tile<T>::CPR / 256;            // 2 / 4 chunks per thread
+    uint4 v[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / Tile<T>::CPR, c = q % Tile<T>::CPR;
+        const int gr = min(row0 + row, nrows - 1);
+        v[it] = *(const uint4*)(g + (int64_t)gr * ld + c * Tile<T>::EPC);
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q / Tile<T>::CPR, c = q % Tile<T>::CPR;
+        *(uint4*)(lds + swz<Tile<T>::RB>(row, c)) = v[it];
+    }
+}
+
+// row fragment s of tile row `row`: 16 bytes at logical chunk s*2 + (lane>>5)
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type row_frag(const char* lds, int row, int s, int lane) {
+    return *(const typename Frag<T>::type*)(lds + swz<Tile<T>::RB>(row, s * 2 + (lane >> 5)));
+}
+
+// column fragment: the MFMA A operand X^T[d][slot] for d = d0 + (lane&31) where the k-slots are the
+// tile rows that acc_frag<T>(., s) of the partner operand owns (see pa_mma.h):
+//   bf16: rows rbase + 16s + 4h + {0..3} and + 8 more;  f32: rows rbase + 8s + 4h + {0..3}
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type col_frag(const char* lds, int rbase, int s, int d0, int lane);
+template <>
+__device__ __forceinline__ bf16x8 col_frag<bf16>(const char* lds, int rbase, int s, int d0, int lane) {
+    const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int r1 = rbase + 16 * s + 4 * h + (p >> 2);
+    const int d = d0 + g * 16 + (p & 3) * 4;                   // first of this lane's 4 source elements
+    const int within = (d & 7) * 2;
+    const bf16x4 lo = lds_tr16(lds + swz128(r1, d >> 3) + within);
+    const bf16x4 hi = lds_tr16(lds + swz128(r1 + 8, d >> 3) + within);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+template <>
+__device__ __forceinline__ f32x4 col_frag<float>(const char* lds, int rbase, int s, int d0, int lane) {
+    const int d = d0 + (lane & 31), h = lane >> 5;
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = rbase + 8 * s + 4 * h + e;
+        f[e] = *(const float*)(lds + swz256(row, d >> 2) + (d & 3) * 4);
+    }
+    return f;
+}
+
+// Transposed store of two 32x32 accumulator tiles acc[db] (lane = owned row, register = d) as rows of
+// 64 contiguous elements: through a per-wave [32][65] f32 LDS slab.
+template <typename T>
+__device__ __forceinline__ void store_rows_T(float* slab, const f32x16 (&acc)[2], float mul, T* gout,
+                                             int64_t ld, int row0, int nvalid_rows, int lane) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(lane & 31) * 65 + db * 32 + acc_row(r, lane)] = acc[db][r] * mul;
+    // same-wave LDS RAW is ordered; mul may differ per lane (1/l), applied before the transpose
+    for (int row = 0; row < 32; ++row) {
+        if (row < nvalid_rows) gout[(int64_t)(row0 + row) * ld + lane] = from_f32<T>(slab[row * 65 + lane]);
+    }
+}
+
+static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
+                                                       int ldo, float* __restrict__ lse, int H, int N, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + Tile<T>::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * HD;
+    const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;      // q of token 0 of this (b,h)
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = min(q0 + (lane & 31), N - 1);
+
+    typename Frag<T>::type qf[Tile<T>::NFRAG];
+#pragma unroll
+    for (int s = 0; s < Tile<T>::NFRAG; ++s)
+        qf[s] = *(const typename Frag<T>::type*)(base + (int64_t)qrow * ldqkv + (s * 2 + (lane >> 5)) * Tile<T>::EPC);
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = scale * LOG2E;
+
+    const int ntiles = (N + TROWS - 1) / TROWS;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        load_tile<T>(sK, base + D, ldqkv, kt * TROWS, N, tid);
+        load_tile<T>(sV, base + 2 * D, ldqkv, kt * TROWS, N, tid);
+        __syncthreads();
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < Tile<T>::NFRAG; ++st)
+                mma32<T>(s[kb], row_frag<T>(sK, kb * 32 + (lane & 31), st, lane), qf[st]);
+        }
+        // online softmax; this lane owns query (lane&31) and 16 of the 32 keys of each key block
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * TROWS + kb * 32 + acc_row(r, lane);
+                const float v = key < N ? s[kb][r] * sl2 : -INFINITY;
+                s[kb][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[kb][r] - m_new);
+                s[kb][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < AccSteps<T>::N; ++st) {
+                const typename Frag<T>::type pf = acc_frag<T>(s[kb], st);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma32<T>(oacc[db], col_frag<T>(sV, kb * 32, st, db * 32, lane), pf);
+            }
+    }
+    __syncthreads();   // tiles are dead; reuse LDS for the transposed store
+    if (q0 < N) {
+        if (lane < 32 && q0 + lane < N) lse[(int64_t)bh * N + q0 + lane] = m_run * LN2 + __logf(l_run);
+        store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, 1.0f / l_run, o + (int64_t)b * N * ldo + h * HD,
+                        ldo, q0, min(32, N - q0), lane);
+    }
+}
+
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]   (one wave per token row, all heads)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
+                                                         float* __restrict__ delta, int B, int H, int N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (int64_t)B * N) return;
+    const int b = (int)(m / N), n = (int)(m % N);
+    for (int h = 0; h < H; ++h) {
+        const float v = to_f32<T>(o[m * ldo + h * HD + lane]) * to_f32<T>(d_o[m * ldo + h * HD + lane]);
+        const float s = wave_sum(v);
+        if (lane == 0) delta[((int64_t)b * H + h) * N + n] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: dK, dV.  Workgroup owns 128 keys (lane = key); queries stream through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
+                                                            const T* __restrict__ d_o, int ldo,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sDO = smem + Tile<T>::BYTES;
+    float* sLse = (float*)(smem + 2 * Tile<T>::BYTES);
+    float* sDelta = sLse + TROWS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * HD;
+    const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
+    const T* dobase = d_o + (int64_t)b * N * ldo + h * HD;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int key = k0 + (lane & 31);
+    const int krow = min(key, N - 1);
+
+    typename Frag<T>::type kf[Tile<T>::NFRAG], vf[Tile<T>::NFRAG];
+#pragma unroll
+    for (int s = 0; s < Tile<T>::NFRAG; ++s) {
+        const int off = (s * 2 + (lane >> 5)) * Tile<T>::EPC;
+        kf[s] = *(const typename Frag<T>::type*)(base + D + (int64_t)krow * ldqkv + off);
+        vf[s] = *(const typename Frag<T>::type*)(base + 2 * D + (int64_t)krow * ldqkv + off);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    const float sl2 = scale * LOG2E;
+
+    const int ntiles = (N + TROWS - 1) / TROWS;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        __syncthreads();
+        load_tile<T>(sQ, base, ldqkv, qt * TROWS, N, tid);
+        load_tile<T>(sDO, dobase, ldo, qt * TROWS, N, tid);
+        if (tid < TROWS) {
+            const int q = min(qt * TROWS + tid, N - 1);
+            sLse[tid] = lse[(int64_t)bh * N + q] * LOG2E;
+            sDelta[tid] = delta[(int64_t)bh * N + q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sa, dpa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dpa[r] = 0.f; }
+            // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (A rows = q, B cols = key = lane)
+#pragma unroll
+            for (int st = 0; st < Tile<T>::NFRAG; ++st) {
+                mma32<T>(sa, row_frag<T>(sQ, qb * 32 + (lane & 31), st, lane), kf[st]);
+                mma32<T>(dpa, row_frag<T>(sDO, qb * 32 + (lane & 31), st, lane), vf[st]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qb * 32 + acc_row(r, lane);
+                const bool valid = (qt * TROWS + ql < N) && (key < N);
+                const float p = valid ? exp2f(sa[r] * sl2 - sLse[ql]) : 0.f;
+                sa[r] = p;                                   // P
+                dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;  // dS
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int st = 0; st < AccSteps<T>::N; ++st) {
+                const typename Frag<T>::type pf = acc_frag<T>(sa, st), dsf = acc_frag<T>(dpa, st);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    mma32<T>(dv[db], col_frag<T>(sDO, qb * 32, st, db * 32, lane), pf);
+                    mma32<T>(dk[db], col_frag<T>(sQ, qb * 32, st, db * 32, lane), dsf);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (k0 < N) {
+        float* slab = (float*)smem + wave * (32 * 65);
+        T* out = dqkv + (int64_t)b * N * lddqkv + h * HD;
+        store_rows_T<T>(slab, dk, 1.0f, out + D, lddqkv, k0, min(32, N - k0), lane);
+        store_rows_T<T>(slab, dv, 1.0f, out + 2 * D, lddqkv, k0, min(32, N - k0), lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: dQ.  Workgroup owns 128 queries (lane = query); keys stream through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
+                                                          const T* __restrict__ d_o, int ldo,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + Tile<T>::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * HD;
+    const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
+    const T* dobase = d_o + (int64_t)b * N * ldo + h * HD;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const int qrow = min(q, N - 1);
+
+    typename Frag<T>::type qf[Tile<T>::NFRAG], dof[Tile<T>::NFRAG];
+#pragma unroll
+    for (int s = 0; s < Tile<T>::NFRAG; ++s) {
+        const int off = (s * 2 + (lane >> 5)) * Tile<T>::EPC;
+        qf[s] = *(const typename Frag<T>::type*)(base + (int64_t)qrow * ldqkv + off);
+        dof[s] = *(const typename Frag<T>::type*)(dobase + (int64_t)qrow * ldo + off);
+    }
+    const float lse2 = lse[(int64_t)bh * N + qrow] * LOG2E;
+    const float dlt = delta[(int64_t)bh * N + qrow];
+    f32x16 dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    const float sl2 = scale * LOG2E;
+
+    const int ntiles = (N + TROWS - 1) / TROWS;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        load_tile<T>(sK, base + D, ldqkv, kt * TROWS, N, tid);
+        load_tile<T>(sV, base + 2 * D, ldqkv, kt * TROWS, N, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 sa, dpa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dpa[r] = 0.f; }
+            // S^T[key][q] = K Q^T ; dP^T[key][q] = V dO^T
+#pragma unroll
+            for (int st = 0; st < Tile<T>::NFRAG; ++st) {
+                mma32<T>(sa, row_frag<T>(sK, kb * 32 + (lane & 31), st, lane), qf[st]);
+                mma32<T>(dpa, row_frag<T>(sV, kb * 32 + (lane & 31), st, lane), dof[st]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * TROWS + kb * 32 + acc_row(r, lane);
+                const float p = key < N ? exp2f(sa[r] * sl2 - lse2) : 0.f;
+                dpa[r] = p * (dpa[r] - dlt) * scale;   // dS^T
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int st = 0; st < AccSteps<T>::N; ++st) {
+                const typename Frag<T>::type dsf = acc_frag<T>(dpa, st);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma32<T>(dq[db], col_frag<T>(sK, kb * 32, st, db * 32, lane), dsf);
+            }
+        }
+    }
+    __syncthreads();
+    if (q0 < N)
+        store_rows_T<T>((float*)smem + wave * (32 * 65), dq, 1.0f, dqkv + (int64_t)b * N * lddqkv + h * HD,
+                        lddqkv, q0, min(32, N - q0), lane);
+}
+
+template <typename T> static size_t fwd_lds() { return std::max<size_t>(2 * Tile<T>::BYTES, SLAB_BYTES); }
+template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * Tile<T>::BYTES + 2 * TROWS * 4, SLAB_BYTES); }
+
+template <typename T>
+static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+                           float scale, hipStream_t st) {
+    dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, scale);
+    return check_launch();
+}
+
+template <typename T>
+static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo, const float* lse,
+                           float* delta, void* dqkv, int lddqkv, int B, int H, int N, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)cdiv((int64_t)B * N, 4)), dim3(256), 0, st,
+                       (const T*)o, (const T*)d_o, ldo, delta, B, H, N);
+    int rc = check_launch();
+    if (rc) return rc;
+    dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
+                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, scale);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
+                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, scale);
+    return check_launch();
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+static bool attn_args_ok(int ld, int dtype) {
+    const int es = dtype == PA_BF16 ? 2 : 4;
+    return (ld * es) % 16 == 0;
+}
+
+extern "C" int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+                                float scale, int dtype, void* stream) {
+    if (!qkv || !o || !lse || B <= 0 || H <= 0 || N <= 0) return PA_EINVAL;
+    if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype)) return PA_EUNSUPPORTED;
+    if (dtype == PA_BF16) return attention_fwd_t<bf16>(qkv, ldqkv, o, ldo, lse, B, H, N, scale, (hipStream_t)stream);
+    if (dtype == PA_F32) return attention_fwd_t<float>(qkv, ldqkv, o, ldo, lse, B, H, N, scale, (hipStream_t)stream);
+    return PA_EINVAL;
+}
+
+extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
+                                const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N,
+                                float scale, int dtype, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0) return PA_EINVAL;
+    if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype) || !attn_args_ok(lddqkv, dtype)) return PA_EUNSUPPORTED;
+    if (dtype == PA_BF16) return attention_bwd_t<bf16>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, scale, (hipStream_t)stream);
+    if (dtype == PA_F32) return attention_bwd_t<float>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, scale, (hipStream_t)stream);
+    return PA_EINVAL;
+}

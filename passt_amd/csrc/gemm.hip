@@ -1,0 +1,377 @@
+// MFMA GEMM  C[M][N] = A[M][K] * B[N][K]^T  with fused epilogues, plus the small data-movement
+// kernels around it (convert, transpose, split-K reduce, row/column sums).
+//
+// Replaces the reference's nn.Linear calls (models/passt.py:285,288,345,359), the patch-embed
+// conv as an im2col GEMM (:323) and their autograd gradients.  See include/passt_amd.h.
+//
+// Tiling (gfx950): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave =
+// 2x2 MFMA 32x32 tiles, 64 f32 accumulators per lane); K consumed 128 BYTES per step (64 bf16 /
+// 32 f32) so the same LDS image and read pattern serve both dtypes.  Operand tiles are staged
+// HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered (2 x 32 KiB); the
+// LDS image is lane-linear, so the bank-conflict XOR swizzle is applied on the per-lane SOURCE
+// address and again on the ds_read_b128 address (guide rule 21).
+#include <algorithm>
+
+#include "pa_mma.h"
+
+namespace pa {
+
+static constexpr int BM = 128, BN = 128, KB = 128;  // KB: K bytes per step
+static constexpr int TILE_BYTES = BM * KB;            // 16 KiB per operand tile
+static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB
+
+
+// 8 consecutive elements <-> 8 floats; `cnt` < 8 takes the scalar tail path.
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8], int cnt);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], int cnt) {
+    if (cnt >= 8) {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        for (int e = 0; e < cnt; ++e) p[e] = v[e];
+    }
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8], int cnt) {
+    if (cnt >= 8) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *(bf16x8*)p = o;
+    } else {
+        for (int e = 0; e < cnt; ++e) p[e] = (bf16)v[e];
+    }
+}
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8], int cnt);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8], int cnt) {
+    if (cnt >= 8) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < cnt ? p[e] : 0.f;
+    }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8], int cnt) {
+    if (cnt >= 8) {
+        const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < cnt ? (float)p[e] : 0.f;
+    }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_n,
+                                                      const int nwg, const int ksteps_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int bid = xcd_swizzle(blockIdx.x, nwg);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int ks_end = min(ksteps_total, ks_begin + ksteps_per_split);
+    const int nsteps = ks_end - ks_begin;
+
+    // ---- per-lane source addresses of the 8 global->LDS copies this wave issues per stage ----
+    // wave-instruction i (0..3) of this wave fills LDS bytes [(wave*4+i)*1024, +1024) of a tile:
+    // lane -> physical 16-byte chunk q = (wave*4+i)*64 + lane -> row q>>3, physical chunk q&7,
+    // which must hold logical chunk (q&7) ^ swz_f128(row).
+    const char* srcA[4];
+    const char* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (wave * 4 + i) * 64 + lane;
+        const int row = q >> 3;
+        const int c = (q & 7) ^ swz_f128(row);
+        const int gm = min(m0 + row, a.M - 1);
+        const int gn = min(n0 + row, a.N - 1);
+        srcA[i] = (const char*)a.A + ((int64_t)gm * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        srcB[i] = (const char*)a.B + ((int64_t)gn * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+    }
+    auto stage = [&](int buf, int step) {
+        char* sA = smem + buf * (2 * TILE_BYTES) + wave * 4096;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
+                (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KB),
+                (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // read offsets: row = w*64 + i*32 + (lane&31); swz_f128(row) == swz_f128(lane) for every i
+    const int rsw = swz_f128(lane);
+    const int offA = (wr * 64 + (lane & 31)) * 128;
+    const int offB = (wc * 64 + (lane & 31)) * 128;
+    const int half = lane >> 5;
+
+    if (nsteps > 0) stage(0, 0);
+    for (int t = 0; t < nsteps; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of tile t landed
+        __syncthreads();                         // everyone's copies landed; buffer (t+1)&1 is free
+        if (t + 1 < nsteps) stage((t + 1) & 1, t + 1);
+        const char* sA = smem + (t & 1) * (2 * TILE_BYTES);
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((ks * 2 + half) ^ rsw) << 4;
+            typename Frag<T>::type fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+                fb[i] = *(const typename Frag<T>::type*)(sB + offB + i * 32 * 128 + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+        }
+    }
+
+    // ---- epilogue: accumulators -> LDS (per-wave [32][68] f32 slab) -> 8-wide row vectors -------
+    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused below
+    float* slab = (float*)smem + wave * (32 * 68);
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int ncol = n0 + wc * 64 + ecol;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if constexpr (EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU) {
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = (ncol + e < a.N) ? a.bias[ncol + e] : 0.f;
+        }
+    }
+    const bool full_n = ncol + 8 <= a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[acc_row(r, lane) * 68 + j * 32 + (lane & 31)] = acc[i][j][r];
+        // same-wave LDS RAW: the LDS queue is in order per wave; no barrier needed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + erow;
+            const int m = m0 + wr * 64 + i * 32 + row;
+            const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
+            const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
+            if (m >= a.M || ncol >= a.N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias8[e]; v[4 + e] = hi[e] + bias8[4 + e]; }
+            if constexpr (EPI == PA_EPI_STORE) {
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_GELU) {
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[e])));
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+                store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_RESID) {
+                int64_t rrow = m, orow = m;
+                if (a.row_mod > 0) {
+                    rrow = m % a.row_mod;
+                    orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + rrow;
+                }
+                float rs[8];
+                load8<float>(a.resid + rrow * a.ldr + ncol, rs, full_n ? 8 : a.N - ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rs[e];
+                store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_DGELU) {
+                float pre[8];
+                load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, pre, full_n ? 8 : a.N - ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(pre[e]);
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+            } else {  // PA_EPI_PARTIAL
+                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v,
+                              full_n ? 8 : a.N - ncol);
+            }
+        }
+    }
+}
+
+template <typename T, int EPI>
+static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
+    const int tiles_m = (int)cdiv(a.M, BM), tiles_n = (int)cdiv(a.N, BN);
+    const int nwg = tiles_m * tiles_n;
+    const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
+    const int per = (int)cdiv(ksteps, splits);
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(nwg, splits), dim3(256), GEMM_LDS, st, a,
+                       tiles_n, nwg, per);
+    return check_launch();
+}
+
+template <typename T>
+static int dispatch_gemm(const pa_gemm_args& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case PA_EPI_STORE: return a.out_lp ? launch_gemm<T, PA_EPI_STORE>(a, st) : PA_EINVAL;
+        case PA_EPI_GELU: return (a.out_lp && a.out_lp2) ? launch_gemm<T, PA_EPI_GELU>(a, st) : PA_EINVAL;
+        case PA_EPI_RESID: return (a.out_f32 && a.resid) ? launch_gemm<T, PA_EPI_RESID>(a, st) : PA_EINVAL;
+        case PA_EPI_DGELU: return (a.out_lp && a.aux) ? launch_gemm<T, PA_EPI_DGELU>(a, st) : PA_EINVAL;
+        case PA_EPI_PARTIAL: return (a.out_f32 && a.split_k >= 1) ? launch_gemm<T, PA_EPI_PARTIAL>(a, st) : PA_EINVAL;
+    }
+    return PA_EINVAL;
+}
+
+// ---- elementwise / data movement -----------------------------------------------------------
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *(const float4*)(in + i);
+        out[i] = from_f32<T>(v.x); out[i + 1] = from_f32<T>(v.y);
+        out[i + 2] = from_f32<T>(v.z); out[i + 3] = from_f32<T>(v.w);
+    }
+    if (i < n) for (int64_t k = i; k < n && k < i + 4; ++k) out[k] = from_f32<T>(in[k]);
+}
+
+// 64x64 tile transpose through LDS; out[c][r] = in[r][c], zero fill for r in [R, ldo).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, int R, int C, int ldi,
+                                                        TO* __restrict__ out, int ldo) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? to_f32<TI>(in[(int64_t)r * ldi + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < ldo) out[(int64_t)c * ldo + r] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t n,
+                                       float* __restrict__ out, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
+        out[i] = s;
+    }
+}
+
+// one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int R, int C, int ld,
+                                                     float* __restrict__ out, int accumulate) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += to_f32<T>(in[(int64_t)row * ld + c]);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = (accumulate ? out[row] : 0.f) + s;
+}
+
+__global__ void colsum_f32_kernel(const float* __restrict__ in, int R, int C, int ld,
+                                  float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += in[(int64_t)r * ld + c];
+    out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" int pa_gemm_nt(const pa_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || a->M <= 0 || a->N <= 0 || a->K <= 0) return PA_EINVAL;
+    const size_t es = a->dtype == PA_BF16 ? 2 : 4;
+    if ((a->K * es) % KB) return PA_EUNSUPPORTED;
+    if ((a->lda * es) % 16 || (a->ldb * es) % 16) return PA_EUNSUPPORTED;
+    if (a->epilogue != PA_EPI_PARTIAL && a->split_k > 1) return PA_EINVAL;
+    // the epilogue moves 8-element vectors: every output / auxiliary leading dimension must keep
+    // them 16-byte aligned
+    if (a->out_lp && a->ldolp % 8) return PA_EUNSUPPORTED;
+    if (a->out_lp2 && a->ldolp2 % 8) return PA_EUNSUPPORTED;
+    if (a->out_f32 && a->ldo32 % 4) return PA_EUNSUPPORTED;
+    if (a->resid && a->ldr % 4) return PA_EUNSUPPORTED;
+    if (a->aux && a->ldaux % 8) return PA_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == PA_BF16) return dispatch_gemm<bf16>(*a, st);
+    if (a->dtype == PA_F32) return dispatch_gemm<float>(*a, st);
+    return PA_EINVAL;
+}
+
+extern "C" int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, void* stream) {
+    if (!in || !out || n < 0) return PA_EINVAL;
+    if (n == 0) return PA_OK;
+    const int blocks = (int)std::min<int64_t>(cdiv(n, 1024), 4096);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(convert_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
+    else if (dtype == PA_F32) hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n);
+    else return PA_EINVAL;
+    return check_launch();
+}
+
+extern "C" int pa_transpose(const void* in, int in_dtype, int R, int C, int ldi, void* out,
+                            int out_dtype, int ldo, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || ldo < R || ldi < C) return PA_EINVAL;
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(ldo, 64));
+    hipStream_t st = (hipStream_t)stream;
+#define PA_TR(TI, TO) hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(256), 0, st, (const TI*)in, R, C, ldi, (TO*)out, ldo)
+    if (in_dtype == PA_F32 && out_dtype == PA_F32) PA_TR(float, float);
+    else if (in_dtype == PA_F32 && out_dtype == PA_BF16) PA_TR(float, bf16);
+    else if (in_dtype == PA_BF16 && out_dtype == PA_BF16) PA_TR(bf16, bf16);
+    else if (in_dtype == PA_BF16 && out_dtype == PA_F32) PA_TR(bf16, float);
+    else return PA_EINVAL;
+#undef PA_TR
+    return check_launch();
+}
+
+extern "C" int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out,
+                                  int accumulate, void* stream) {
+    if (!partial || !out || splits < 1 || n <= 0) return PA_EINVAL;
+    const int blocks = (int)std::min<int64_t>(cdiv(n, 256), 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, n, out, accumulate);
+    return check_launch();
+}
+
+extern "C" int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate,
+                         void* stream) {
+    if (!in || !out || R <= 0 || C <= 0) return PA_EINVAL;
+    dim3 grid((unsigned)cdiv(R, 4));
+    if (dtype == PA_BF16) hipLaunchKernelGGL(rowsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, R, C, ld, out, accumulate);
+    else if (dtype == PA_F32) hipLaunchKernelGGL(rowsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, R, C, ld, out, accumulate);
+    else return PA_EINVAL;
+    return check_launch();
+}
+
+extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate,
+                             void* stream) {
+    if (!in || !out || R <= 0 || C <= 0) return PA_EINVAL;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out, accumulate);
+    return check_launch();
+}

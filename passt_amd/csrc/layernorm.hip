@@ -1,0 +1,215 @@
+// LayerNorm forward / backward over the last dimension, one 64-lane wave per row.
+// Reference: nn.LayerNorm in Block (models/passt.py:369,373,378-379, eps 1e-6 from :426), the final
+// norm (:450,:570) and head.0 (:463, eps 1e-5).  HBM-bound: every row is read once with float4
+// loads, kept in registers for the two-pass mean/variance (torch's biased variance), written once.
+#include <algorithm>
+
+#include "pa_common.h"
+
+namespace pa {
+
+static constexpr int LN_MAXV = 8;       // float4 per lane -> D <= 2048 (kernels are instantiated for 1,2,3,4,8)
+static constexpr int LN_BWD_BLOCKS = 512;
+
+template <typename T> __device__ __forceinline__ void store4(T* p, const float4& v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float4& v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float4& v) {
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *(bf16x4*)p = o;
+}
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float* xr = x + (int64_t)row * D;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) { v[i] = *(const float4*)(xr + 4 * c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float r = rsqrtf(wave_sum(s2) / (float)D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = r;
+    }
+    T* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+            float4 o;
+            o.x = (v[i].x - mu) * r * g.x + b.x; o.y = (v[i].y - mu) * r * g.y + b.y;
+            o.z = (v[i].z - mu) * r * g.z + b.z; o.w = (v[i].w - mu) * r * g.w + b.w;
+            store4<T>(yr + 4 * c, o);
+        }
+    }
+}
+
+// dx = dres + rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat));  per-block partial
+// column sums of dy*xhat (dgamma) and dy (dbeta) go to ws[block][2][D].
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, T* __restrict__ dx_lp,
+                                                     float* __restrict__ ws, int M, int D) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    float4 g[MAXV], ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        g[i] = c < nv ? *(const float4*)(gamma + 4 * c) : make_float4(0, 0, 0, 0);
+        ag[i] = make_float4(0, 0, 0, 0);
+        ab[i] = make_float4(0, 0, 0, 0);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], r = rstd[row];
+        const int64_t base = (int64_t)row * D;
+        float4 xh[MAXV], gy[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 xv = *(const float4*)(x + base + 4 * c);
+                const float4 d = load4<T>(dy + base + 4 * c);
+                xh[i] = make_float4((xv.x - mu) * r, (xv.y - mu) * r, (xv.z - mu) * r, (xv.w - mu) * r);
+                gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+                s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+                s2 += (gy[i].x * xh[i].x + gy[i].y * xh[i].y) + (gy[i].z * xh[i].z + gy[i].w * xh[i].w);
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o;
+                o.x = r * (gy[i].x - c1 - xh[i].x * c2); o.y = r * (gy[i].y - c1 - xh[i].y * c2);
+                o.z = r * (gy[i].z - c1 - xh[i].z * c2); o.w = r * (gy[i].w - c1 - xh[i].w * c2);
+                if (dres) {
+                    const float4 dr = *(const float4*)(dres + base + 4 * c);
+                    o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
+                }
+                *(float4*)(dx + base + 4 * c) = o;
+                if (dx_lp) store4<T>(dx_lp + base + 4 * c, o);
+            }
+        }
+    }
+    // block reduce of the 4 waves' partials, then one partial row per block
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            *(float4*)(red + (wave * 2 + 0) * D + 4 * c) = ag[i];
+            *(float4*)(red + (wave * 2 + 1) * D + 4 * c) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * D; k += 256) {
+        const int which = k / D, c = k - which * D;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * D + c];
+        ws[(int64_t)blockIdx.x * 2 * D + k] = s;
+    }
+}
+
+// out[which][c] (+)= sum_b ws[b][which][c];  block = 64 columns x 4 row groups
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + cx;   // index into [2][D]
+    float s = 0.f;
+    if (k < 2 * D)
+        for (int b = ry; b < nblk; b += 4) s += ws[(int64_t)b * 2 * D + k];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && k < 2 * D) {
+        s = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        float* out = k < D ? dgamma + k : dbeta + (k - D);
+        *out = (accumulate ? *out : 0.f) + s;
+    }
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" int pa_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int dtype,
+                                float* mean, float* rstd, int M, int D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || D <= 0) return PA_EINVAL;
+    if (D % 4 || D > LN_MAXV * 256) return PA_EUNSUPPORTED;
+    dim3 grid((unsigned)cdiv(M, 4));
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    const int nvl = (int)cdiv(D, 256);
+#define PA_LN_FWD(V)                                                                                              \
+    do {                                                                                                          \
+        if (dtype == PA_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16, V>), grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps); \
+        else hipLaunchKernelGGL((ln_fwd_kernel<float, V>), grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (float*)y, mean, rstd, M, D, eps); \
+    } while (0)
+    if (nvl <= 1) PA_LN_FWD(1); else if (nvl == 2) PA_LN_FWD(2); else if (nvl == 3) PA_LN_FWD(3);
+    else if (nvl == 4) PA_LN_FWD(4); else PA_LN_FWD(8);
+#undef PA_LN_FWD
+    return check_launch();
+}
+
+static int ln_bwd_blocks(int M) { return (int)std::min<int64_t>(LN_BWD_BLOCKS, cdiv(M, 4)); }
+
+extern "C" int64_t pa_layernorm_bwd_ws_floats(int M, int D) { return (int64_t)ln_bwd_blocks(M) * 2 * D; }
+
+extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gamma,
+                                const float* mean, const float* rstd, const float* dres, float* dx,
+                                void* dx_lp, float* dgamma, float* dbeta, int accumulate, float* ws,
+                                int M, int D, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || M <= 0 || D <= 0) return PA_EINVAL;
+    if (D % 4 || D > LN_MAXV * 256) return PA_EUNSUPPORTED;
+    const int nblk = ln_bwd_blocks(M);
+    const size_t lds = (size_t)8 * D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    const int nvl = (int)cdiv(D, 256);
+#define PA_LN_BWD(V)                                                                                              \
+    do {                                                                                                          \
+        if (dtype == PA_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16, V>), dim3(nblk), dim3(256), lds, st, (const bf16*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lp, ws, M, D); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, V>), dim3(nblk), dim3(256), lds, st, (const float*)dy, x, gamma, mean, rstd, dres, dx, (float*)dx_lp, ws, M, D); \
+    } while (0)
+    if (nvl <= 1) PA_LN_BWD(1); else if (nvl == 2) PA_LN_BWD(2); else if (nvl == 3) PA_LN_BWD(3);
+    else if (nvl == 4) PA_LN_BWD(4); else PA_LN_BWD(8);
+#undef PA_LN_BWD
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 64)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, accumulate);
+    return check_launch();
+}

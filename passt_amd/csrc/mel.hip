@@ -1,0 +1,228 @@
+// Fused log-mel front end for gfx950: waveform -> (B, n_mels, T) in ONE kernel.
+// Reference: AugmentMelSTFT.forward, models/preprocess.py:57-86
+//   :59     pre-emphasis conv1d [-0.97, 1]            -> fused into the LDS loader
+//   :60-61  torch.stft(n_fft 1024, hop, hann(win) centred, center=True/reflect) -> LDS-resident
+//           radix-8 FFT: one 64-lane wave transforms one frame (1024 real = 512 complex points,
+//           8 complex points per lane, three in-register 8-point DFTs, two LDS exchanges)
+//   :62     power spectrum                            -> never leaves LDS
+//   :71-76  kaldi mel filterbank (dense 128x513 matmul in the reference) -> sparse band product:
+//           each FFT bin feeds at most two adjacent triangles (weights u and 1-u)
+//   :78     log(mel + 1e-5), :80-82 SpecAugment masks, :84 (x+4.5)/5 -> epilogue
+// HBM traffic = read the waveform once (+6% halo) and write the mel tile once.
+//
+// Workgroup = 8 waves = 32 consecutive frames of one clip (4 frames per wave); the 32-frame output
+// tile is transposed through LDS so every mel row is written as 128 contiguous bytes.
+#include "pa_common.h"
+
+namespace pa {
+
+static constexpr int NFFT = 1024;
+static constexpr int NC = 512;            // complex points
+static constexpr int FR_PER_WG = 32;
+static constexpr int MEL_WAVES = 8;
+static constexpr int XROW1 = 68;          // exchange-1 row stride (complex) : conflict-free reads
+static constexpr int XROW2 = 72;          // exchange-2 row stride (complex)
+static constexpr int WAVE_SCRATCH = 8 * XROW2 * 8;   // 4608 bytes
+
+struct cf { float x, y; };
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf cmul_negi(cf a) { return {a.y, -a.x}; }   // a * (-i)
+
+// in-place 8-point DFT, natural order in and out:  X[p] = sum_a v[a] exp(-2 pi i a p / 8)
+__device__ __forceinline__ void dft8(cf (&v)[8]) {
+    const float R = 0.70710678118654752440f;
+    const cf s0 = cadd(v[0], v[4]), d0 = csub(v[0], v[4]);
+    const cf s1 = cadd(v[1], v[5]), d1 = csub(v[1], v[5]);
+    const cf s2 = cadd(v[2], v[6]), d2 = csub(v[2], v[6]);
+    const cf s3 = cadd(v[3], v[7]), d3 = csub(v[3], v[7]);
+    const cf t0 = cadd(s0, s2), t1 = csub(s0, s2), t2 = cadd(s1, s3), t3 = cmul_negi(csub(s1, s3));
+    v[0] = cadd(t0, t2); v[4] = csub(t0, t2); v[2] = cadd(t1, t3); v[6] = csub(t1, t3);
+    const cf e0 = d0;
+    const cf e1 = {(d1.x + d1.y) * R, (d1.y - d1.x) * R};      // d1 * (1 - i)/sqrt2
+    const cf e2 = cmul_negi(d2);
+    const cf e3 = {(d3.y - d3.x) * R, -(d3.x + d3.y) * R};     // d3 * (-1 - i)/sqrt2
+    const cf u0 = cadd(e0, e2), u1 = csub(e0, e2), u2 = cadd(e1, e3), u3 = cmul_negi(csub(e1, e3));
+    v[1] = cadd(u0, u2); v[5] = csub(u0, u2); v[3] = cadd(u1, u3); v[7] = csub(u1, u3);
+}
+
+// exp(-2 pi i j / 1024) for j in [0, 1024) from the half table
+__device__ __forceinline__ cf tw1024(const float2* __restrict__ tw, int j) {
+    const float2 t = tw[j & 511];
+    return (j & 512) ? cf{-t.x, -t.y} : cf{t.x, t.y};
+}
+
+__global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restrict__ wave, int L,
+                                                            const float* __restrict__ window,
+                                                            const float* __restrict__ bin_mel,
+                                                            const float2* __restrict__ twiddle,
+                                                            float* __restrict__ out, const pa_mel_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int span = (FR_PER_WG - 1) * p.hop + NFFT;
+    float* sSig = (float*)smem;                                        // [span] pre-emphasised, reflect-padded
+    char* sScr = smem + ((span * 4 + 15) & ~15);                       // [8 waves][WAVE_SCRATCH]
+    float* sU = (float*)(sScr + MEL_WAVES * WAVE_SCRATCH);             // [512] up-slope weight of bin k
+    int* sJ = (int*)(sU + NC);                                         // [512] triangle index of bin k
+    int* sS = sJ + NC;                                                 // [n_mels + 3] first bin with j >= b
+    float* sOut = (float*)(sS + 132);                                  // [n_mels][33]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * FR_PER_WG;
+    const int T = p.n_frames;
+    const int Ly = L - 1;
+    const float* x = wave + (int64_t)b * L;
+
+    // ---- stage the signal span: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2 ----
+    for (int j = tid; j < span; j += 512) {
+        int i = f0 * p.hop + j - NFFT / 2;
+        if (i < 0) i = -i;
+        if (i >= Ly) i = 2 * (Ly - 1) - i;
+        i = max(0, min(i, Ly - 1));
+        sSig[j] = x[i + 1] - p.preemph * x[i];
+    }
+    // ---- filterbank geometry for this call's (fmin, fmax): bin k -> triangle j_k, weight u_k ----
+    for (int k = tid; k < NC; k += 512) {
+        const float t = (bin_mel[k] - p.mel_low) * p.inv_mel_delta;
+        const float fl = floorf(t);
+        sJ[k] = (int)fmaxf(fminf(fl, 100000.f), -1.f);
+        sU[k] = t - fl;
+    }
+    __syncthreads();
+    if (tid <= p.n_mels + 2) {       // sS[b] = #bins with j_k < b  (j_k is non-decreasing in k)
+        int lo = 0, hi = NC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sJ[mid] < tid) lo = mid + 1; else hi = mid;
+        }
+        sS[tid] = lo;
+    }
+    __syncthreads();
+
+    // ---- per-lane constants ----
+    cf tw1[8], tw2[8], tw3[8];
+    float win[16];
+    {
+        const int m = lane;                  // stage-1 role: m
+        const int c = lane >> 3;             // stage-2 role: (c, p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            tw1[q] = tw1024(twiddle, 2 * m * q);          // W512^(m q)
+            tw2[q] = tw1024(twiddle, 16 * c * q);         // W64^(c q)
+            tw3[q] = tw1024(twiddle, lane + 64 * q);      // W1024^k, k = lane + 64 q
+            win[2 * q] = window[2 * (64 * q + m)];
+            win[2 * q + 1] = window[2 * (64 * q + m) + 1];
+        }
+    }
+    cf* scr = (cf*)(sScr + wv * WAVE_SCRATCH);
+    float* pw = (float*)scr;                 // power spectrum overlays the scratch (513 floats)
+
+    for (int fi = 0; fi < FR_PER_WG / MEL_WAVES; ++fi) {
+        const int fl = wv * (FR_PER_WG / MEL_WAVES) + fi;
+        const int frame = f0 + fl;
+        if (frame >= T) break;               // wave-uniform
+        const float* sig = sSig + fl * p.hop;
+        cf v[8];
+        // stage 1: lane m holds z[64a + m], a = 0..7  (z[n] = y[2n] + i y[2n+1], windowed)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int n = 64 * a + lane;
+            v[a] = {sig[2 * n] * win[2 * a], sig[2 * n + 1] * win[2 * a + 1]};
+        }
+        dft8(v);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw1[q]);
+        // exchange 1: Y[m][p] -> lane (c, p') reads Y[8b + c][p'], b = 0..7   (layout [p][m], stride 68)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) scr[q * XROW1 + lane] = v[q];
+        {
+            const int c = lane >> 3, pp = lane & 7;
+#pragma unroll
+            for (int bq = 0; bq < 8; ++bq) v[bq] = scr[pp * XROW1 + 8 * bq + c];
+        }
+        dft8(v);                              // over b -> r
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw2[q]);
+        // exchange 2: U[c][p][r] (lane = c*8+p holds r = 0..7) -> lane' = r*8 + p reads c = 0..7
+#pragma unroll
+        for (int q = 0; q < 8; ++q) scr[q * XROW2 + lane] = v[q];
+        {
+            const int r = lane >> 3, pp = lane & 7;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = scr[r * XROW2 + c * 8 + pp];
+        }
+        dft8(v);                              // over c -> s ; lane' holds Z[lane' + 64 s]
+        // untangle the packed real FFT: needs Z[k] and Z[512-k]
+#pragma unroll
+        for (int s = 0; s < 8; ++s) scr[lane + 64 * s] = v[s];
+        float pk[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = lane + 64 * s;
+            const cf zk = v[s];
+            const cf zc = scr[(NC - k) & (NC - 1)];            // Z[512-k] (Z[512] == Z[0])
+            const cf e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};         // (Z[k] + conj Z[N-k]) / 2
+            const cf o = {0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x)};        // (Z[k] - conj Z[N-k]) / (2i)
+            const cf xo = cmul(o, tw3[s]);
+            const cf X = cadd(e, xo);
+            pk[s] = X.x * X.x + X.y * X.y;
+        }
+        const cf z0 = scr[0];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pw[lane + 64 * s] = pk[s];    // all reads of scr are issued above
+        if (lane == 0) { const float ny = z0.x - z0.y; pw[NC] = ny * ny; }
+        // sparse mel bands: this lane owns bands `lane` and `n_mels-1-lane` (one narrow + one wide)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int band = h == 0 ? lane : p.n_mels - 1 - lane;
+            // h == 0 covers bands 0..63; h == 1 covers the remaining 64..n_mels-1 in reverse
+            const bool mine = h == 0 ? band < p.n_mels : band >= 64;
+            if (!mine) continue;
+            float acc = 0.f;
+            const int k0 = sS[band], k1 = sS[band + 1], k2 = sS[band + 2];
+            for (int k = k0; k < k1; ++k) acc += pw[k] * sU[k];
+            for (int k = k1; k < k2; ++k) acc += pw[k] * (1.0f - sU[k]);
+            sOut[band * (FR_PER_WG + 1) + fl] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: log, SpecAugment masks, affine; rows of 32 frames = 128 contiguous bytes ----
+    for (int idx = tid; idx < p.n_mels * FR_PER_WG; idx += 512) {
+        const int mel = idx / FR_PER_WG, fl = idx % FR_PER_WG;
+        const int t = f0 + fl;
+        if (t >= T) continue;
+        float v = __logf(sOut[mel * (FR_PER_WG + 1) + fl] + p.log_eps);
+        const bool masked = (mel >= p.fmask_start && mel < p.fmask_end) || (t >= p.tmask_start && t < p.tmask_end);
+        if (masked) v = 0.f;
+        out[((int64_t)b * p.n_mels + mel) * T + t] = (v + p.out_add) * p.out_scale;
+    }
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" int pa_mel_num_frames(int L, int hop) { return (L < 2 || hop <= 0) ? 0 : 1 + (L - 1) / hop; }
+
+extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float* window, const float* bin_mel,
+                                   const float* twiddle, float* out, const pa_mel_params* p, void* stream) {
+    if (!wave || !window || !bin_mel || !twiddle || !out || !p || B <= 0) return PA_EINVAL;
+    if (p->n_fft != NFFT || p->n_mels < 4 || p->n_mels > 128 || p->hop <= 0 || p->hop > NFFT) return PA_EUNSUPPORTED;
+    if (L - 1 <= NFFT / 2) return PA_EUNSUPPORTED;          // reflect padding needs L-1 > n_fft/2 (torch.stft rule)
+    if (p->n_frames != pa_mel_num_frames(L, p->hop)) return PA_EINVAL;
+    const int span = (FR_PER_WG - 1) * p->hop + NFFT;
+    const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH + NC * 4 + NC * 4 + 132 * 4 +
+                       (size_t)p->n_mels * (FR_PER_WG + 1) * 4;
+    if (lds > 160 * 1024) return PA_EUNSUPPORTED;
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)mel_frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024) == hipSuccess;
+    }();
+    (void)attr_set;
+    dim3 grid((unsigned)cdiv(p->n_frames, FR_PER_WG), (unsigned)B);
+    hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(512), lds, (hipStream_t)stream, wave, L, window, bin_mel,
+                       (const float2*)twiddle, out, *p);
+    return check_launch();
+}
