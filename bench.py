@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the PaSST training hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): clips/s of 10 s @ 32 kHz, forward+backward, passt_s
+(passt_s_swa_p16_128_ap476: 768/12/12, patch 16 stride 10, s_patchout_t=40 s_patchout_f=4 => 474
+tokens), batch 64 per GPU (configs[1]; weak scaling: per-GPU batch fixed).  One "step" = one full
+training step on one resident synthetic batch: waveforms (64, 320000) -> fused mel front end (train
+mode: random fmin/fmax, SpecAugment masks) -> mixup -> PaSST forward (bf16 MFMA, f32 residual stream)
+-> BCE loss -> full backward -> [N>1: per-block RCCL all-reduce overlapped with backward] -> AdamW on
+all 86 M parameters.  Nothing is skipped or cached inside the timed region.
+
+Besides the contract line it reports
+  roofline     : the dominant kernel (the MFMA GEMM family), timed per launch with HIP events on the
+                 launch stream inside the timed region; achieved = algorithmic FLOPs / measured time,
+                 against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline : the oracle (CPU restatement of the reference, oracle/passt_oracle.py) timed on this
+                 host on a bounded sample of the same workload (train-mode fwd+bwd, B=4 per iteration).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+ARCH = "passt_s_swa_p16_128_ap476"
+CLIP_SAMPLES = 320000                # 10 s @ 32 kHz
+
+
+def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
+    """per block 24 N D^2 + 4 N^2 D, patch embed 2 P 256 D (kept patches only),
+    fwd+bwd = 3x fwd."""
+    fwd = depth * (24 * N * D * D + 4 * N * N * D) + 2 * kept_patches * 256 * D
+    return 3 * fwd / 1e9
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle (port of the reference) fwd+bwd in train mode on this host's cores."""
+    from oracle import detgen
+    from oracle import passt_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.make_cfg(s_patchout_t=40, s_patchout_f=4)
+    sd = O.to_torch(detgen.passt_state_dict(cfg, 1), requires_grad=True)
+    B = 4
+    x = torch.from_numpy(detgen.uniform(1, "x", (B, 1, 128, 998), -1, 1))
+    y = (torch.rand(B, 527) < 0.005).float()
+    iters, t0 = 0, None
+    while True:
+        if iters == 1:
+            t0 = time.time()            # first iteration is warm-up
+        lo, _ = O.passt_forward(sd, x, cfg, training=True)
+        O.bce_loss(lo, y).backward()
+        iters += 1
+        if t0 is not None and (time.time() - t0 > budget_s or iters >= 9):
+            break
+    dt = time.time() - t0
+    n = (iters - 1) * B
+    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters - 1} train-mode fwd+bwd iterations of batch {B} (net only, fp32 torch CPU "
+                      f"restatement of the reference), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mel", action="store_true", help="feed spectrograms (reference model_speed_test style)")
+    ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sgd"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import passt_amd
+    from passt_amd import ops
+    from passt_amd.train import TrainStep
+
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = passt_amd.get_model(arch=ARCH, pretrained=False, s_patchout_t=40, s_patchout_f=4).to(dev).train()
+        mel = None if args.no_mel else passt_amd.AugmentMelSTFT(
+            n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, freqm=48, timem=192, fmin=0.0, fmax=None,
+            fmin_aug_range=10, fmax_aug_range=2000).to(dev).train()      # ex_audioset.py:66-69 config
+    net.precision = args.precision
+    if world > 1:                      # identical replicas
+        for p in net.parameters():
+            dist.broadcast(p.data, 0)
+    ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True)
+    B = args.batch
+    if args.no_mel:
+        x = torch.randn(B, 1, 128, 998, device=dev)
+    else:
+        x = (torch.rand(B, 1, CLIP_SAMPLES, device=dev) * 2 - 1) * 0.1    # U(-1,1)*0.1
+    y = (torch.rand(B, 527, device=dev) < 2.7 / 527).float()              # ~2.7 labels per clip
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(args.warmup):
+            ts.step(x, y)
+        barrier()
+        ops.GEMM_PROFILE = {} if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = ts.step(x, y)
+        barrier()
+        t1 = time.perf_counter()
+    prof = ops.GEMM_PROFILE
+    ops.GEMM_PROFILE = None
+    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    loss_v = float(loss.item())
+    assert np.isfinite(loss_v), "non-finite loss"
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        gflop_clip = algorithmic_gflop_per_clip()
+        out = {
+            "metric": "clips/s (10s@32k) fwd+bwd passt_s", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{ARCH} train step (mel front end + mixup + fwd + BCE + bwd + {args.optimizer}), "
+                                   f"768/12/12, 474 tokens (s_patchout_t=40,f=4), random-init weights",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "input": "spectrogram (B,1,128,998)" if args.no_mel else "waveform (B,1,320000) f32 resident in HBM"},
+            "algorithmic_gflop_per_clip": round(gflop_clip, 2),
+            "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "loss": round(loss_v, 6),
+        }
+        if prof:
+            tot_ms, tot_flop, n, per_kind = 0.0, 0.0, 0, {}
+            for kind, recs in prof.items():
+                ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+                fl = sum(f for _, _, f in recs)
+                per_kind[kind] = {"launches": len(recs), "avg_us": round(1e3 * ms / len(recs), 2),
+                                  "tflops": round(fl / ms / 1e9, 1)}
+                tot_ms += ms
+                tot_flop += fl
+                n += len(recs)
+            achieved = tot_flop / tot_ms / 1e9
+            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "pa::gemm_nt_kernel<bf16,*> (all epilogues; 2*M*N*K algorithmic FLOPs per launch)",
+                               "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
+                               "gemm_time_share_of_step": round(tot_ms / (1e3 * elapsed), 3),
+                               "per_epilogue": per_kind}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

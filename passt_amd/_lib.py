@@ -1,0 +1,96 @@
+"""ctypes binding of libpasst_amd.so (C ABI: include/passt_amd.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, we raise.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C passt_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpasst_amd.so")
+
+PA_F32, PA_BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_PARTIAL = 0, 1, 2, 3, 4
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class MelParams(C.Structure):
+    _fields_ = [("n_fft", i32), ("hop", i32), ("n_mels", i32), ("n_frames", i32),
+                ("preemph", f32), ("mel_low", f32), ("inv_mel_delta", f32), ("log_eps", f32),
+                ("out_add", f32), ("out_scale", f32),
+                ("fmask_start", i32), ("fmask_end", i32), ("tmask_start", i32), ("tmask_end", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("epilogue", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("A", vp), ("B", vp), ("bias", vp), ("resid", vp),
+                ("ldr", i32), ("row_mod", i32), ("out_batch_rows", i32), ("out_row_off", i32),
+                ("aux", vp), ("ldaux", i32), ("out_f32", vp), ("ldo32", i32), ("out_lp", vp),
+                ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/passt_amd.h declares
+SIGNATURES = {
+    "pa_abi_version": (i32, []),
+    "pa_error_string": (C.c_char_p, [i32]),
+    "pa_last_hip_error": (C.c_char_p, []),
+    "pa_mel_num_frames": (i32, [i32, i32]),
+    "pa_mel_frontend_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, C.POINTER(MelParams), vp]),
+    "pa_convert_f32": (i32, [vp, vp, i64, i32, vp]),
+    "pa_transpose": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
+    "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
+    "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "pa_reduce_partials": (i32, [vp, i32, i64, vp, i32, vp]),
+    "pa_rowsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "pa_colsum_f32": (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    "pa_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp]),
+    "pa_attention_bwd": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "pa_patch_gather": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "pa_patch_pos_table": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "pa_patch_bwd": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp]),
+    "pa_head_pre_fwd": (i32, [vp, i32, i32, i32, vp, vp, f32, vp, vp, f32, vp, vp, vp, vp]),
+    "pa_linear_f32_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "pa_linear_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "pa_head_pre_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "pa_bce_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+    "pa_mixup": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    "pa_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "pa_sgd": (i32, [vp, vp, i64, f32, vp]),
+}
+
+_lib = None
+
+
+class PasstAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is not built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PasstAmdError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run "
+            "`make -C passt_amd/csrc` (needs hipcc, --offload-arch=gfx950).  passt_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    if lib.pa_abi_version() != 1:
+        raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        lib = load()
+        msg = lib.pa_error_string(rc).decode()
+        if rc == -3:
+            msg += ": " + lib.pa_last_hip_error().decode()
+        raise PasstAmdError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,307 @@
+"""Tensor-level wrappers over the C ABI (include/passt_amd.h).
+
+Every function takes CUDA(HIP) torch tensors, passes raw device pointers + the current stream to
+libpasst_amd.so and returns the output tensors it allocated (torch is the allocator only).
+No fallback: a non-CUDA tensor or a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_DGELU, EPI_GELU, EPI_PARTIAL, EPI_RESID, EPI_STORE, PA_BF16, PA_F32,
+                   GemmArgs, MelParams, check)
+
+TORCH_DTYPE = {PA_F32: torch.float32, PA_BF16: torch.bfloat16}
+PA_DTYPE = {torch.float32: PA_F32, torch.bfloat16: PA_BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PasstAmdError("passt_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+# bench.py sets this to a dict to time every GEMM launch with HIP events on the launch stream:
+# {epilogue: [(start_event, end_event, algorithmic_flops)]}
+GEMM_PROFILE = None
+_EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
+
+
+def kpad(dtype):
+    """GEMM K granularity in elements (128 bytes)."""
+    return 64 if dtype == PA_BF16 else 32
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ---- front end -----------------------------------------------------------------------------
+def mel_frontend(wave, window, bin_mel, twiddle, params: MelParams):
+    B, L = wave.shape
+    out = torch.empty((B, params.n_mels, params.n_frames), device=wave.device, dtype=torch.float32)
+    check(_lib.load().pa_mel_frontend_fwd(_p(wave), B, L, _p(window), _p(bin_mel), _p(twiddle), _p(out),
+                                          C.byref(params), _stream()), "pa_mel_frontend_fwd")
+    return out
+
+
+# ---- staging ---------------------------------------------------------------------------------
+def convert(x_f32, dtype):
+    if dtype == PA_F32:
+        return x_f32
+    out = torch.empty(x_f32.shape, device=x_f32.device, dtype=TORCH_DTYPE[dtype])
+    check(_lib.load().pa_convert_f32(_p(x_f32), _p(out), x_f32.numel(), dtype, _stream()), "pa_convert_f32")
+    return out
+
+
+def transpose(x, out_dtype, ldo=None, out=None):
+    """x [R][C] (contiguous rows, any supported dtype) -> [C][ldo] (ldo >= R, zero padded)."""
+    R, Cc = x.shape
+    ldo = R if ldo is None else ldo
+    if out is None:
+        out = torch.empty((Cc, ldo), device=x.device, dtype=TORCH_DTYPE[out_dtype])
+    check(_lib.load().pa_transpose(_p(x), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out), out_dtype, ldo,
+                                   _stream()), "pa_transpose")
+    return out
+
+
+# ---- layer norm ------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, dtype, save_stats=True):
+    M, D = x.shape
+    y = torch.empty((M, D), device=x.device, dtype=TORCH_DTYPE[dtype])
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    check(_lib.load().pa_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), dtype, _p(mean), _p(rstd), M, D, eps,
+                                       _stream()), "pa_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumulate=False):
+    """Returns (dx f32, dx_lp or None).  dgamma/dbeta are written in place."""
+    M, D = x.shape
+    dtype = PA_DTYPE[dy.dtype]
+    lib = _lib.load()
+    dx = torch.empty((M, D), device=x.device, dtype=torch.float32)
+    dx_lp = torch.empty((M, D), device=x.device, dtype=dy.dtype) if (want_lp and dtype != PA_F32) else None
+    ws = torch.empty(lib.pa_layernorm_bwd_ws_floats(M, D), device=x.device, dtype=torch.float32)
+    check(lib.pa_layernorm_bwd(_p(dy), dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dx_lp),
+                               _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, D, _stream()), "pa_layernorm_bwd")
+    return dx, (dx if dtype == PA_F32 else dx_lp)
+
+
+# ---- GEMM ------------------------------------------------------------------------------------
+def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
+            out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None):
+    """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h."""
+    a = GemmArgs()
+    a.dtype, a.epilogue = dtype, epilogue
+    a.M = A.shape[0] if M is None else M
+    a.N = B.shape[0] if N is None else N
+    a.K = A.shape[1] if K is None else K
+    a.lda, a.ldb = A.stride(0), B.stride(0)
+    a.A, a.B = _p(A), _p(B)
+    a.bias = _p(bias)
+    a.resid = _p(resid)
+    a.ldr = resid.stride(0) if resid is not None else 0
+    a.row_mod, a.out_batch_rows, a.out_row_off = row_mod, out_batch_rows, out_row_off
+    a.aux = _p(aux)
+    a.ldaux = aux.stride(0) if aux is not None else 0
+    a.out_f32 = _p(out_f32)
+    a.ldo32 = (out_f32.stride(-2) if out_f32 is not None else 0)
+    a.out_lp = _p(out_lp)
+    a.ldolp = out_lp.stride(0) if out_lp is not None else 0
+    a.out_lp2 = _p(out_lp2)
+    a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
+    a.split_k = split_k
+    if GEMM_PROFILE is None:
+        check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
+        return
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
+    ev1.record()
+    GEMM_PROFILE.setdefault(_EPI_NAME[epilogue], []).append((ev0, ev1, 2.0 * a.M * a.N * a.K))
+
+
+def linear(x_lp, W_lp, bias, dtype):
+    """out_lp[M][N] = x W^T + b"""
+    out = torch.empty((x_lp.shape[0], W_lp.shape[0]), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+    gemm_nt(x_lp, W_lp, dtype, EPI_STORE, bias=bias, out_lp=out)
+    return out
+
+
+def linear_gelu(x_lp, W_lp, bias, dtype):
+    M, N = x_lp.shape[0], W_lp.shape[0]
+    pre = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+    act = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+    gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
+    return pre, act
+
+
+def linear_resid(x_lp, W_lp, bias, resid_f32, dtype, out=None):
+    """out_f32[M][N] = resid + x W^T + b"""
+    if out is None:
+        out = torch.empty_like(resid_f32)
+    gemm_nt(x_lp, W_lp, dtype, EPI_RESID, bias=bias, resid=resid_f32, out_f32=out)
+    return out
+
+
+def pick_split_k(n_out_tiles, ksteps):
+    """Enough workgroups to fill 256 CUs x 2, at least 8 K-steps per slice."""
+    s = max(1, min(64, (768 + n_out_tiles - 1) // n_out_tiles))
+    return max(1, min(s, ksteps // 8 if ksteps >= 8 else 1))
+
+
+def wgrad(dY_t, X_t, out_f32, dtype, accumulate=False, partial_ws=None):
+    """out[N][K] (+)= dY_t[N][Mp] . X_t[K][Mp]^T  -- the weight gradient dY^T X from transposed,
+    zero-padded operands; deterministic split-K (f32 partial slabs + ordered reduction)."""
+    N, Mp = dY_t.shape
+    K = X_t.shape[0]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    ksteps = Mp // kpad(dtype)
+    S = pick_split_k(tiles, ksteps)
+    need = S * N * K
+    if partial_ws is None or partial_ws.numel() < need:
+        partial_ws = torch.empty(need, device=dY_t.device, dtype=torch.float32)
+    part = partial_ws[:need].view(S, N, K)
+    gemm_nt(dY_t, X_t, dtype, EPI_PARTIAL, out_f32=part, split_k=S)
+    check(_lib.load().pa_reduce_partials(_p(part), S, N * K, _p(out_f32), int(accumulate), _stream()),
+          "pa_reduce_partials")
+    return partial_ws
+
+
+def rowsum(x, out_f32, ncols=None, accumulate=False):
+    R, Cc = x.shape
+    check(_lib.load().pa_rowsum(_p(x), PA_DTYPE[x.dtype], R, Cc if ncols is None else ncols, x.stride(0),
+                                _p(out_f32), int(accumulate), _stream()), "pa_rowsum")
+
+
+def colsum_f32(x, out_f32, accumulate=False):
+    R, Cc = x.shape
+    check(_lib.load().pa_colsum_f32(_p(x), R, Cc, x.stride(0), _p(out_f32), int(accumulate), _stream()),
+          "pa_colsum_f32")
+
+
+# ---- attention -------------------------------------------------------------------------------
+def attention_fwd(qkv, B, H, N, scale):
+    dtype = PA_DTYPE[qkv.dtype]
+    D = H * 64
+    o = torch.empty((B * N, D), device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty((B * H * N,), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().pa_attention_fwd(_p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, scale, dtype,
+                                       _stream()), "pa_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, B, H, N, scale):
+    dtype = PA_DTYPE[qkv.dtype]
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    check(_lib.load().pa_attention_bwd(_p(qkv), qkv.stride(0), _p(o), _p(d_o), o.stride(0), _p(lse), _p(delta),
+                                       _p(dqkv), dqkv.stride(0), B, H, N, scale, dtype, _stream()),
+          "pa_attention_bwd")
+    return dqkv
+
+
+# ---- patch embedding -------------------------------------------------------------------------
+def patch_gather(x, patch_f, patch_t, P, fstride, tstride, dtype):
+    B, _, F, T = x.shape
+    Np = patch_f.numel()
+    cols = torch.empty((B * Np, P * P), device=x.device, dtype=TORCH_DTYPE[dtype])
+    check(_lib.load().pa_patch_gather(_p(x), B, F, T, _p(patch_f), _p(patch_t), Np, P, fstride, tstride, _p(cols),
+                                      dtype, _stream()), "pa_patch_gather")
+    return cols
+
+
+def patch_pos_table(bias, time_pos, freq_pos, patch_f, patch_t, toff, cls, dist, npe, tok):
+    B, Ntok, D = tok.shape
+    Np = patch_f.numel()
+    Tpe, Fpe = time_pos.shape[-1], freq_pos.shape[-2]
+    table = torch.empty((Np, D), device=tok.device, dtype=torch.float32)
+    check(_lib.load().pa_patch_pos_table(_p(bias), _p(time_pos), Tpe, _p(freq_pos), Fpe, _p(patch_f), _p(patch_t),
+                                         Np, toff, D, _p(table), _p(cls), _p(dist), _p(npe), _p(tok), B, Ntok,
+                                         _stream()), "pa_patch_pos_table")
+    return table
+
+
+def patch_bwd(dtok, patch_f, patch_t, toff, Tpe, Fpe, d_cls, d_dist, d_npe, d_bias, d_tpos, d_fpos, dtype,
+              accumulate=False):
+    B, Ntok, D = dtok.shape
+    Np = patch_f.numel()
+    gsum = torch.empty((Ntok, D), device=dtok.device, dtype=torch.float32)
+    dpatch = torch.empty((B * Np, D), device=dtok.device, dtype=TORCH_DTYPE[dtype])
+    check(_lib.load().pa_patch_bwd(_p(dtok), B, Ntok, D, _p(patch_f), _p(patch_t), Np, toff, Tpe, Fpe, _p(gsum),
+                                   _p(d_cls), _p(d_dist), _p(d_npe), _p(d_bias), _p(d_tpos), _p(d_fpos),
+                                   int(accumulate), _p(dpatch), dtype, _stream()), "pa_patch_bwd")
+    return dpatch
+
+
+# ---- head / loss -----------------------------------------------------------------------------
+def head_pre_fwd(x, norm_g, norm_b, eps_norm, hg, hb, eps_head):
+    B, Ntok, D = x.shape
+    feat = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    hn = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    stats = torch.empty((B, 6), device=x.device, dtype=torch.float32)
+    check(_lib.load().pa_head_pre_fwd(_p(x), B, Ntok, D, _p(norm_g), _p(norm_b), eps_norm, _p(hg), _p(hb), eps_head,
+                                      _p(feat), _p(hn), _p(stats), _stream()), "pa_head_pre_fwd")
+    return feat, hn, stats
+
+
+def head_pre_bwd(dhn, dfeat, x, feat, norm_g, hg, stats):
+    B, Ntok, D = x.shape
+    dx = torch.empty((B, Ntok, D), device=x.device, dtype=torch.float32)
+    part = torch.empty((B, 4 * D), device=x.device, dtype=torch.float32)
+    check(_lib.load().pa_head_pre_bwd(_p(dhn), _p(dfeat), _p(x), _p(feat), B, Ntok, D, _p(norm_g), _p(hg), _p(stats),
+                                      _p(dx), _p(part), _stream()), "pa_head_pre_bwd")
+    return dx, part
+
+
+def linear_f32_fwd(x, W, b):
+    B, D = x.shape
+    Cc = W.shape[0]
+    y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    check(_lib.load().pa_linear_f32_fwd(_p(x), _p(W), _p(b), _p(y), B, Cc, D, _stream()), "pa_linear_f32_fwd")
+    return y
+
+
+def linear_f32_bwd(dy, x, W, dW, db, accumulate=False):
+    B, Cc = dy.shape
+    D = x.shape[1]
+    dx = torch.empty((B, D), device=x.device, dtype=torch.float32)
+    check(_lib.load().pa_linear_f32_bwd(_p(dy), _p(x), _p(W), _p(dx), _p(dW), _p(db), int(accumulate), B, Cc, D,
+                                        _stream()), "pa_linear_f32_bwd")
+    return dx
+
+
+def bce_fwd_bwd(logits, target, grad_scale=1.0):
+    B, Cc = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits)
+    ws = torch.empty(1 + (B * Cc + 255) // 256, device=logits.device, dtype=torch.float32)
+    check(_lib.load().pa_bce_fwd_bwd(_p(logits), _p(target), B, Cc, grad_scale, _p(loss), _p(dlogits), _p(ws),
+                                     _stream()), "pa_bce_fwd_bwd")
+    return loss, dlogits
+
+
+# ---- caller glue -----------------------------------------------------------------------------
+def mixup(x, perm_i32, lam):
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    check(_lib.load().pa_mixup(_p(x), _p(perm_i32), _p(lam), _p(out), B, x[0].numel(), _stream()), "pa_mixup")
+    return out
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    check(_lib.load().pa_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _stream()),
+          "pa_adamw")
+
+
+def sgd(p, g, lr):
+    check(_lib.load().pa_sgd(_p(p), _p(g), p.numel(), lr, _stream()), "pa_sgd")

@@ -1,0 +1,561 @@
+"""PaSST on MI355X: drop-in for the reference's ``models/passt.py``.
+
+Same public surface as the reference (kkoutini/PaSST, file:line below are the reference's):
+``PaSST`` (models/passt.py:383) with identical constructor kwargs, ``state_dict`` keys/shapes
+(SURVEY.md App. D), parameter order and ``forward(x) -> (logits, features)`` (:576-595);
+``get_model`` (:957-1018) / ``get_model_passt`` (hear21passt alias), ``get_ensemble_model``
+(:1039-1045), ``EnsembelerModel`` (:1021-1037), ``fix_embedding_layer``/``lighten_model``
+(:924-954) and a ``model_ing`` ingredient when ``ba3l`` is importable.
+
+Underneath, nothing of torch's operator library is used on the hot path: ``forward`` /
+``backward`` sequence the hand-written gfx950 kernels of libpasst_amd.so (include/passt_amd.h)
+through one ``torch.autograd.Function``; the sub-modules below (``nn.Linear`` ...) are
+*parameter containers only*, kept so that ``state_dict()``, ``.parameters()`` order,
+``deepcopy`` (SWA), ``print(model)`` and checkpoint loading behave exactly like the reference.
+
+Precision: plain call = exact-f32 MFMA path (matches the reference's fp32 forward/backward
+<= 1e-3 rel); inside ``torch.autocast("cuda")`` or with ``model.precision = "bf16"`` = bf16 MFMA
+with f32 accumulation, f32 residual stream / LayerNorm / softmax (the reference's AMP regime).
+Patchout indices are drawn with the reference's own torch CPU RNG calls in the reference's order
+(:513-553), hence bit-exact.
+"""
+import math
+import warnings
+from collections import OrderedDict
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import EPI_DGELU, EPI_RESID, EPI_STORE, PA_BF16, PA_F32, PasstAmdError
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (never executed on the product path)
+# --------------------------------------------------------------------------------------------
+class PatchEmbed(nn.Module):
+    """Parameter container mirroring models/passt.py:298-328 (Conv2d 1->D, k=patch, stride)."""
+
+    def __init__(self, img_size=224, patch_size=16, stride=16, in_chans=3, embed_dim=768, norm_layer=None,
+                 flatten=True):
+        super().__init__()
+        self.img_size = to_2tuple(img_size)
+        self.patch_size = to_2tuple(patch_size)
+        self.stride = to_2tuple(stride)
+        self.grid_size = (self.img_size[0] // self.stride[0], self.img_size[1] // self.stride[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.stride)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+
+def _init_vit_weights(module):
+    """models/passt.py:598-629 as reached through ``self.apply`` (no name => generic branch)."""
+    if isinstance(module, nn.Linear):
+        nn.init.trunc_normal_(module.weight, std=.02)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
+
+
+# --------------------------------------------------------------------------------------------
+# host-side index logic (bit-exact with the reference: same torch CPU RNG calls, same order)
+# --------------------------------------------------------------------------------------------
+def draw_patchout(model, F_dim, T_dim):
+    """models/passt.py:513-553.  Returns (toff, T_eff, idx_t, idx_f, idx_u) (numpy / None)."""
+    Tpe = model.time_new_pos_embed.shape[-1]
+    toff, T_eff = 0, T_dim
+    if T_dim < Tpe:
+        if model.training:
+            toff = torch.randint(1 + Tpe - T_dim, (1,)).item()                         # :516
+    else:
+        warnings.warn(f"the patches shape:{(F_dim, T_dim)} are larger than the expected time encodings "
+                      f"{tuple(model.time_new_pos_embed.shape)}, x will be cut")         # :524-526
+        T_eff = Tpe
+    idx_t = idx_f = idx_u = None
+    T_cur, F_cur = T_eff, F_dim
+    if model.training and model.s_patchout_t:
+        idx_t = torch.randperm(T_dim)[:T_dim - model.s_patchout_t].sort().values.numpy()   # :535
+        if idx_t.size and idx_t.max() >= T_eff:
+            raise IndexError("time patchout index out of range (reference would fail at models/passt.py:536)")
+        T_cur = idx_t.size
+    if model.training and model.s_patchout_f:
+        idx_f = torch.randperm(F_dim)[:F_dim - model.s_patchout_f].sort().values.numpy()   # :541
+        F_cur = idx_f.size
+    if model.training and model.u_patchout:
+        S = F_cur * T_cur
+        idx_u = torch.randperm(S)[:S - model.u_patchout].sort().values.numpy()             # :551
+    return toff, T_eff, idx_t, idx_f, idx_u
+
+
+def kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u):
+    """Grid coordinates of the surviving patches in sequence order (frequency-major flatten, :546)."""
+    ts = np.arange(T_eff) if idx_t is None else idx_t
+    fs = np.arange(F_dim) if idx_f is None else idx_f
+    pf = np.repeat(fs, ts.size)
+    pt = np.tile(ts, fs.size)
+    if idx_u is not None:
+        pf, pt = pf[idx_u], pt[idx_u]
+    return pf.astype(np.int32), pt.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# the kernel sequence
+# --------------------------------------------------------------------------------------------
+class _Staged:
+    """Per-dtype GEMM-ready copies of the weights (bf16 cast and/or transposes), re-made only when a
+    parameter changed (``_version`` bump by the optimizer / load_state_dict)."""
+
+    def __init__(self):
+        self.cache = {}
+        self.epoch = 0      # bumped by optimizers that update parameters through raw pointers
+
+    def get(self, p, dtype, transposed):
+        key = (id(p), dtype, transposed)
+        ver = (p._version, p.data_ptr(), self.epoch)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = p.detach()
+        w2 = w.reshape(w.shape[0], -1)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        if transposed:
+            out = ops.transpose(w2, dtype)
+        else:
+            out = ops.convert(w2, dtype)
+        self.cache[key] = (ver, out)
+        return out
+
+
+def _precision(model):
+    if model.precision is not None:
+        return {"fp32": PA_F32, "f32": PA_F32, "bf16": PA_BF16}[model.precision]
+    return PA_BF16 if torch.is_autocast_enabled() else PA_F32
+
+
+def passt_forward(model, x, save):
+    """Kernel sequence of PaSST.forward (:576-595).  Returns (logits, features, ctx)."""
+    if not x.is_cuda:
+        raise PasstAmdError("passt_amd.PaSST runs on a HIP device only (no CPU fallback); got a CPU tensor")
+    dt = _precision(model)
+    st = model._staged
+    x = x.contiguous().float()
+    B, Cin, F, T = x.shape
+    P, (fs, ts) = model.patch_embed.patch_size[0], model.patch_embed.stride
+    if not (F == model.patch_embed.img_size[0] and T == model.patch_embed.img_size[1]):
+        warnings.warn(f"Input image size ({F}*{T}) doesn't match model "
+                      f"({model.patch_embed.img_size[0]}*{model.patch_embed.img_size[1]}).")   # :320-321
+    F_dim, T_dim = (F - P) // fs + 1, (T - P) // ts + 1
+    Tpe, Fpe = model.time_new_pos_embed.shape[-1], model.freq_new_pos_embed.shape[-2]
+    if F_dim != Fpe:
+        raise RuntimeError(f"patch grid has {F_dim} frequency rows but freq_new_pos_embed has {Fpe}")
+    toff, T_eff, idx_t, idx_f, idx_u = draw_patchout(model, F_dim, T_dim)
+    pf_np, pt_np = kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u)
+    pf = torch.from_numpy(pf_np).to(x.device, non_blocking=True)
+    pt = torch.from_numpy(pt_np).to(x.device, non_blocking=True)
+    D, H, depth = model.embed_dim, model.num_heads, len(model.blocks)
+    Np = pf_np.size
+    Ntok, M = Np + 2, B * (Np + 2)
+    scale = (D // H) ** -0.5
+
+    # patch embedding: gather-first im2col GEMM, epilogue adds bias + time/freq positional rows and
+    # scatters to token rows 2.. ; rows 0,1 = cls/dist + new_pos_embed                 (:323,:527-564)
+    cols = ops.patch_gather(x, pf, pt, P, fs, ts, dt)
+    tok = torch.empty((B, Ntok, D), device=x.device, dtype=torch.float32)
+    table = ops.patch_pos_table(model.patch_embed.proj.bias, model.time_new_pos_embed, model.freq_new_pos_embed,
+                                pf, pt, toff, model.cls_token, model.dist_token, model.new_pos_embed, tok)
+    ops.gemm_nt(cols, st.get(model.patch_embed.proj.weight, dt, False), dt, EPI_RESID, resid=table, out_f32=tok,
+                row_mod=Np, out_batch_rows=Ntok, out_row_off=2)
+
+    xs = tok.view(M, D)
+    saved = []
+    for blk in model.blocks:
+        ln1, mean1, rstd1 = ops.layernorm_fwd(xs, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save)
+        qkv = ops.linear(ln1, st.get(blk.attn.qkv.weight, dt, False), blk.attn.qkv.bias, dt)
+        att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale)
+        x_mid = ops.linear_resid(att, st.get(blk.attn.proj.weight, dt, False), blk.attn.proj.bias, xs, dt)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save)
+        h_pre, h_act = ops.linear_gelu(ln2, st.get(blk.mlp.fc1.weight, dt, False), blk.mlp.fc1.bias, dt)
+        x_out = ops.linear_resid(h_act, st.get(blk.mlp.fc2.weight, dt, False), blk.mlp.fc2.bias, x_mid, dt)
+        if save:
+            saved.append((xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act))
+        xs = x_out
+    xl = xs.view(B, Ntok, D)
+    feat, hn, stats = ops.head_pre_fwd(xl, model.norm.weight, model.norm.bias, model.norm.eps, model.head[0].weight,
+                                       model.head[0].bias, model.head[0].eps)
+    logits = ops.linear_f32_fwd(hn, model.head[1].weight, model.head[1].bias)
+    ctx = None
+    if save:
+        ctx = dict(dt=dt, B=B, Ntok=Ntok, Np=Np, pf=pf, pt=pt, toff=toff, cols=cols, saved=saved, xl=xl, feat=feat,
+                   hn=hn, stats=stats, scale=scale)
+    return logits, feat, ctx
+
+
+def _wgrad_pair(dY, X, dW, db, dt, scratch, accumulate):
+    """dW[N][K] = dY^T X, db[N] = colsum(dY) from row-major dY[M][N], X[M][K] (v1: transpose both
+    operands -- zero padded along M -- and run the NT GEMM with deterministic split-K)."""
+    Mrows = dY.shape[0]
+    Mp = ops.round_up(Mrows, ops.kpad(dt))
+    N, K = dY.shape[1], X.shape[1]
+    need_a, need_b = N * Mp, K * Mp
+    if scratch.get("a") is None or scratch["a"].numel() < need_a:
+        scratch["a"] = torch.empty(need_a, device=dY.device, dtype=ops.TORCH_DTYPE[dt])
+    if scratch.get("b") is None or scratch["b"].numel() < need_b:
+        scratch["b"] = torch.empty(need_b, device=dY.device, dtype=ops.TORCH_DTYPE[dt])
+    dYt = ops.transpose(dY, dt, Mp, out=scratch["a"][:need_a].view(N, Mp))
+    Xt = ops.transpose(X, dt, Mp, out=scratch["b"][:need_b].view(K, Mp))
+    scratch["part"] = ops.wgrad(dYt, Xt, dW, dt, accumulate, scratch.get("part"))
+    if db is not None:
+        ops.rowsum(dYt, db, ncols=Mrows, accumulate=accumulate)
+
+
+def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
+    """Backward of passt_forward.  ``grads``: dict param-name -> f32 tensor to OVERWRITE.
+    ``on_block_done(i)`` is called after block i's parameter gradients are enqueued (i = depth for the
+    head, then depth-1 .. 0, then -1 for the patch embedding) -- the hook the data-parallel reducer
+    uses to start all-reducing finished buckets while the rest of the backward runs."""
+    dt, B, Ntok, Np = ctx["dt"], ctx["B"], ctx["Ntok"], ctx["Np"]
+    st = model._staged
+    D, H = model.embed_dim, model.num_heads
+    M = B * Ntok
+    scratch = model._scratch
+    g = grads
+    # head: logits = hn W^T + b ; hn = LN_1e-5(feat) ; feat = mean of the two normed prefix tokens
+    dhn = ops.linear_f32_bwd(dlogits.contiguous(), ctx["hn"], model.head[1].weight, g["head.1.weight"],
+                             g["head.1.bias"])
+    dxl, part = ops.head_pre_bwd(dhn, dfeat, ctx["xl"], ctx["feat"], model.norm.weight, model.head[0].weight,
+                                 ctx["stats"])
+    part4 = part.view(B, 4, D)
+    for j, name in enumerate(("head.0.weight", "head.0.bias", "norm.weight", "norm.bias")):
+        ops.colsum_f32(part4[:, j, :], g[name])
+    if on_block_done:
+        on_block_done(len(model.blocks))
+    dx = dxl.view(M, D)
+    dx_lp = ops.convert(dx, dt)
+    for i in range(len(model.blocks) - 1, -1, -1):
+        blk = model.blocks[i]
+        pfx = f"blocks.{i}."
+        xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = ctx["saved"][i]
+        # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+        _wgrad_pair(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"], dt, scratch, False)
+        d_pre = torch.empty_like(h_pre)
+        ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre)
+        _wgrad_pair(d_pre, ln2, g[pfx + "mlp.fc1.weight"], g[pfx + "mlp.fc1.bias"], dt, scratch, False)
+        d_ln2 = torch.empty_like(ln2)
+        ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
+        del d_pre
+        dx, dx_lp = ops.layernorm_bwd(d_ln2, x_mid, blk.norm2.weight, mean2, rstd2, dx, g[pfx + "norm2.weight"],
+                                      g[pfx + "norm2.bias"], True)
+        # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))
+        _wgrad_pair(dx_lp, att, g[pfx + "attn.proj.weight"], g[pfx + "attn.proj.bias"], dt, scratch, False)
+        d_att = torch.empty_like(att)
+        ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
+        d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"])
+        _wgrad_pair(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], dt, scratch, False)
+        d_ln1 = torch.empty_like(ln1)
+        ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)
+        dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dx, g[pfx + "norm1.weight"],
+                                      g[pfx + "norm1.bias"], i > 0)
+        if on_block_done:
+            on_block_done(i)
+    # ---- patch embedding / positional parameters / prefix tokens
+    Tpe, Fpe = model.time_new_pos_embed.shape[-1], model.freq_new_pos_embed.shape[-2]
+    dpatch = ops.patch_bwd(dx.view(B, Ntok, D), ctx["pf"], ctx["pt"], ctx["toff"], Tpe, Fpe, g["cls_token"],
+                           g["dist_token"], g["new_pos_embed"], g["patch_embed.proj.bias"],
+                           g["time_new_pos_embed"], g["freq_new_pos_embed"], dt)
+    _wgrad_pair(dpatch, ctx["cols"], g["patch_embed.proj.weight"], None, dt, scratch, False)
+    if on_block_done:
+        on_block_done(-1)
+
+
+class _PasstFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are kernel sequences, torch only
+    sees (x, *parameters) -> (logits, features)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        logits, feat, c = passt_forward(model, x, save=True)
+        ctx.model, ctx.c = model, c
+        return logits, feat
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeat):
+        model, c = ctx.model, ctx.c
+        names = model._grad_names
+        flat = torch.empty(model._n_grad_elems, device=dlogits.device, dtype=torch.float32)
+        grads, off = {}, 0
+        for n, p in model.named_parameters():
+            if n in names:
+                grads[n] = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        # a fresh flat buffer per backward: autograd may keep (not copy) the views as .grad
+        passt_backward(model, c, dlogits.contiguous(), None if dfeat is None else dfeat.contiguous(), grads)
+        ctx.c = None
+        out = [None, None]
+        for n, p in model.named_parameters():
+            out.append(grads.get(n) if p.requires_grad else None)
+        return tuple(out)
+
+
+class PaSST(nn.Module):
+    """Same constructor as the reference (models/passt.py:391-395)."""
+
+    def __init__(self, u_patchout=0, s_patchout_t=0, s_patchout_f=0, img_size=(128, 998), patch_size=16, stride=16,
+                 in_chans=1, num_classes=527, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4., qkv_bias=True,
+                 representation_size=None, distilled=False, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 embed_layer=PatchEmbed, norm_layer=None, act_layer=None, weight_init=''):
+        super().__init__()
+        if not distilled:
+            raise NotImplementedError("passt_amd covers the distilled (cls+dist token) PaSST archs -- every "
+                                      "arch get_model() can return (models/passt.py:963-1008)")
+        if in_chans != 1 or drop_rate or attn_drop_rate or drop_path_rate or mlp_ratio != 4. or not qkv_bias \
+                or representation_size:
+            raise NotImplementedError("passt_amd hot path: in_chans=1, no dropout/drop-path, mlp_ratio=4, qkv_bias")
+        if embed_dim % num_heads or embed_dim // num_heads != 64:
+            raise NotImplementedError("attention kernels are built for head_dim 64 (768/12, 1024/16, 384/6 ...)")
+        self.num_classes = num_classes
+        self.u_patchout, self.s_patchout_t, self.s_patchout_f = u_patchout, s_patchout_t, s_patchout_f
+        self.num_features = self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.num_tokens = 2
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        act_layer = act_layer or nn.GELU
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, stride=stride, in_chans=in_chans,
+                                       embed_dim=embed_dim, flatten=False)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.new_pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
+        self.freq_new_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, self.patch_embed.grid_size[0], 1))
+        self.time_new_pos_embed = nn.Parameter(torch.zeros(1, embed_dim, 1, self.patch_embed.grid_size[1]))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, norm_layer=norm_layer,
+                  act_layer=act_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Sequential(nn.LayerNorm(self.num_features),
+                                  nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity())
+        self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
+        self.precision = None          # None: follow torch.autocast; or "fp32" / "bf16"
+        self.init_weights(weight_init)
+        self._reset_runtime()
+
+    # ---- runtime state that must not be deep-copied / pickled (SWA deepcopies the net) ----------
+    def _reset_runtime(self):
+        object.__setattr__(self, "_staged", _Staged())
+        object.__setattr__(self, "_scratch", {})
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy
+        for k, v in self.__dict__.items():
+            if k in ("_staged", "_scratch"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._reset_runtime()
+        return new
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_staged", None)
+        d.pop("_scratch", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._reset_runtime()
+
+    @property
+    def _grad_names(self):
+        return {n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("head_dist.")}
+
+    @property
+    def _n_grad_elems(self):
+        names = self._grad_names
+        return sum(p.numel() for n, p in self.named_parameters() if n in names)
+
+    def init_weights(self, mode=''):
+        """models/passt.py:471-484."""
+        assert mode in ('jax', 'jax_nlhb', 'nlhb', '')
+        nn.init.trunc_normal_(self.new_pos_embed, std=.02)
+        nn.init.trunc_normal_(self.freq_new_pos_embed, std=.02)
+        nn.init.trunc_normal_(self.time_new_pos_embed, std=.02)
+        nn.init.trunc_normal_(self.dist_token, std=.02)
+        if mode.startswith('jax'):
+            raise RuntimeError("Not supported yet")
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit_weights)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'new_pos_embed', 'freq_new_pos_embed', 'time_new_pos_embed', 'cls_token', 'dist_token'}
+
+    def get_classifier(self):
+        return self.head, self.head_dist
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        raise NotImplementedError("reset_classifier drops the head LayerNorm in the reference "
+                                  "(models/passt.py:500-504); build a new model with n_classes instead")
+
+    def forward_features(self, x):
+        raise NotImplementedError("only forward() is on the accelerated path (returns (logits, features))")
+
+    def mark_params_updated(self):
+        """Call after updating parameters through raw device pointers (passt_amd.optim does)."""
+        self._staged.epoch += 1
+
+    def forward(self, x):
+        """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = [p for _, p in self.named_parameters()]
+            return _PasstFunction.apply(self, x, *params)
+        logits, feat, _ = passt_forward(self, x, save=False)
+        return logits, feat
+
+
+# --------------------------------------------------------------------------------------------
+# architecture constructors + get_model  (models/passt.py:734-1018)
+# --------------------------------------------------------------------------------------------
+_ARCHS = {
+    # arch name -> (depth, expected stride, note)
+    "passt_deit_bd_p16_384": (12, None),
+    "passt_s_kd_p16_128_ap486": (12, (10, 10)),
+    "passt_l_kd_p16_128_ap47": (7, (10, 10)),
+    "passt_s_swa_p16_128_ap476": (12, (10, 10)),
+    "passt_s_swa_p16_128_ap4761": (12, (10, 10)),
+    "passt_s_p16_128_ap472": (12, (10, 10)),
+    "passt_s_p16_s16_128_ap468": (12, (16, 16)),
+    "passt_s_swa_p16_s16_128_ap473": (12, (16, 16)),
+    "passt_s_swa_p16_s14_128_ap471": (12, (14, 14)),
+    "passt_s_p16_s14_128_ap469": (12, (14, 14)),
+    "passt_s_swa_p16_s12_128_ap473": (12, (12, 12)),
+    "passt_s_p16_s12_128_ap470": (12, (12, 12)),
+    "passt_s_f128_20sec_p16_s10_ap474": (12, (10, 10)),
+    "passt_s_f128_30sec_p16_s10_ap473": (12, (10, 10)),
+}
+
+
+def fix_embedding_layer(model, embed="default"):
+    if embed != "default":
+        raise NotImplementedError("only embed='default' is reachable in the reference (models/passt.py:924-931)")
+    return model
+
+
+def lighten_model(model, cut_depth=0):
+    """models/passt.py:934-954."""
+    if cut_depth == 0:
+        return model
+    old = list(model.blocks.children())
+    if cut_depth < 0:
+        old = [old[0]] + old[1:-1:-cut_depth] + [old[-1]]
+    else:
+        if len(model.blocks) < cut_depth + 2:
+            raise ValueError(f"Cut depth a VIT with {len(model.blocks)} layers should be between 1 and "
+                             f"{len(model.blocks) - 2}")
+        old = [old[0]] + old[cut_depth + 1:]
+    model.blocks = nn.Sequential(*old)
+    return model
+
+
+def get_model(arch="passt_s_kd_p16_128_ap486", pretrained=True, n_classes=527, in_channels=1, fstride=10, tstride=10,
+              input_fdim=128, input_tdim=998, u_patchout=0, s_patchout_t=0, s_patchout_f=0):
+    """Same signature/defaults as models/passt.py:958-961.  ``pretrained=True`` needs a checkpoint
+    download (vit_helpers.py:85-91) which this offline build cannot do: pass ``pretrained=False`` and
+    ``load_state_dict`` a reference checkpoint (identical keys)."""
+    if arch not in _ARCHS:
+        raise RuntimeError(f"Unknown model {arch}")
+    if pretrained:
+        raise RuntimeError("pretrained=True requires downloading the reference checkpoint (no network here); "
+                           "use pretrained=False and model.load_state_dict(torch.load(<reference .pt>))")
+    depth, want = _ARCHS[arch]
+    stride = (fstride, tstride)
+    if want is not None and stride != want:
+        warnings.warn(f"This model was pre-trained with strides {want}, but now you set (fstride,tstride) to {stride}.")
+    model = PaSST(u_patchout=u_patchout, s_patchout_t=s_patchout_t, s_patchout_f=s_patchout_f,
+                  img_size=(input_fdim, input_tdim), patch_size=16, stride=stride, in_chans=in_channels,
+                  num_classes=n_classes, embed_dim=768, depth=depth, num_heads=12, distilled=True)
+    model = fix_embedding_layer(model)
+    model = lighten_model(model)
+    return model
+
+
+get_model_passt = get_model     # hear21passt's name for the same function (README.md:49,70,77)
+
+
+class EnsembelerModel(nn.Module):
+    """models/passt.py:1021-1037."""
+
+    def __init__(self, models):
+        super().__init__()
+        self.models = nn.ModuleList(models)
+
+    def forward(self, x):
+        all_out = None
+        for m in self.models:
+            out, _ = m(x)
+            all_out = out if all_out is None else out + all_out
+        all_out = all_out / len(self.models)
+        return all_out, all_out
+
+
+def get_ensemble_model(arch_list=[]):
+    models_list = [get_model(arch=a, fstride=f, tstride=t, pretrained=False) for a, f, t in arch_list]
+    return EnsembelerModel(models_list)
+
+
+try:  # the reference exposes these through a sacred/ba3l ingredient (models/passt.py:915-922)
+    from ba3l.ingredients.ingredient import Ingredient  # type: ignore
+
+    model_ing = Ingredient("passt")
+    model_ing.add_config(instance_cmd="get_model")
+    model_ing.command(fix_embedding_layer)
+    model_ing.command(lighten_model)
+    get_model = model_ing.command(get_model)
+    get_ensemble_model = model_ing.command(get_ensemble_model)
+except Exception:  # ba3l not installed: plain functions
+    model_ing = None

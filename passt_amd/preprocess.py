@@ -1,0 +1,97 @@
+"""AugmentMelSTFT on MI355X: drop-in for the reference's ``models/preprocess.py``.
+
+Same constructor kwargs, buffers (non-persistent => empty ``state_dict``), RNG consumption order
+and ``forward(x: (B, L)) -> (B, n_mels, 1 + (L-1)//hop)`` as the reference class
+(models/preprocess.py:19-86).  The whole chain -- pre-emphasis, STFT, power, kaldi mel filterbank,
+log, SpecAugment masks, normalisation -- is ONE fused HIP kernel (pa_mel_frontend_fwd); the host only
+draws the random numbers (same torch CPU RNG calls, same order) and passes five scalars.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MelParams, PasstAmdError
+
+
+def _draw_mask(mask_param, size):
+    """torchaudio.functional.mask_along_axis draws (0.13.1, non-iid path)."""
+    mask_param = min(mask_param, int(size))
+    if mask_param < 1:
+        return 0, 0
+    value = torch.rand(1) * mask_param
+    min_value = torch.rand(1) * (size - value)
+    start = int(min_value.long())
+    return start, start + int(value.long())
+
+
+class AugmentMelSTFT(nn.Module):
+    def __init__(self, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, freqm=48, timem=192,
+                 htk=False, fmin=0.0, fmax=None, norm=1, fmin_aug_range=1, fmax_aug_range=1000):
+        torch.nn.Module.__init__(self)
+        self.win_length, self.n_mels, self.n_fft, self.sr, self.htk, self.fmin = win_length, n_mels, n_fft, sr, htk, fmin
+        if fmax is None:
+            fmax = sr // 2 - fmax_aug_range // 2
+            print(f"Warning: FMAX is None setting to {fmax} ")
+        self.fmax, self.norm, self.hopsize = fmax, norm, hopsize
+        self.register_buffer('window', torch.hann_window(win_length, periodic=False), persistent=False)
+        assert fmin_aug_range >= 1, f"fmin_aug_range={fmin_aug_range} should be >=1; 1 means no augmentation"
+        assert fmax_aug_range >= 1, f"fmax_aug_range={fmax_aug_range} should be >=1; 1 means no augmentation"
+        self.fmin_aug_range, self.fmax_aug_range = fmin_aug_range, fmax_aug_range
+        self.register_buffer("preemphasis_coefficient", torch.as_tensor([[[-.97, 1]]]), persistent=False)
+        # freqm / timem are plain ints here (the reference wraps torchaudio modules; only their
+        # mask_param is used, :47-54)
+        self.freqm, self.timem = int(freqm), int(timem)
+        # constant tables of the fused kernel (f64 -> f32), non-persistent like the reference buffers
+        left = (n_fft - win_length) // 2
+        wpad = torch.zeros(n_fft)
+        wpad[left:left + win_length] = self.window                      # torch.stft centres the window
+        k = torch.arange(n_fft // 2, dtype=torch.float64)
+        bin_mel = 1127.0 * torch.log1p(k * (sr / n_fft) / 700.0)         # kaldi mel of FFT bin k
+        ang = 2.0 * math.pi * k / n_fft
+        tw = torch.stack([torch.cos(ang), -torch.sin(ang)], dim=1)
+        self.register_buffer("_window_padded", wpad, persistent=False)
+        self.register_buffer("_bin_mel", bin_mel.float(), persistent=False)
+        self.register_buffer("_twiddle", tw.float().contiguous(), persistent=False)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise PasstAmdError("passt_amd.AugmentMelSTFT runs on a HIP device only (no CPU fallback)")
+        if x.dim() != 2:
+            raise ValueError("expected (batch, samples)")
+        x = x.contiguous().float()
+        B, L = x.shape
+        # RNG order of the reference: both randint calls always execute (:63-64)
+        fmin = self.fmin + torch.randint(self.fmin_aug_range, (1,)).item()
+        fmax = self.fmax + self.fmax_aug_range // 2 - torch.randint(self.fmax_aug_range, (1,)).item()
+        if not self.training:
+            fmin, fmax = self.fmin, self.fmax
+        p = MelParams()
+        p.n_fft, p.hop, p.n_mels = self.n_fft, self.hopsize, self.n_mels
+        p.n_frames = 1 + (L - 1) // self.hopsize
+        p.preemph = 0.97
+        mel_low = 1127.0 * math.log(1.0 + fmin / 700.0)
+        mel_high = 1127.0 * math.log(1.0 + fmax / 700.0)
+        p.mel_low = mel_low
+        p.inv_mel_delta = (self.n_mels + 1) / (mel_high - mel_low)
+        p.log_eps, p.out_add, p.out_scale = 0.00001, 4.5, 1.0 / 5.0
+        p.fmask_start = p.fmask_end = p.tmask_start = p.tmask_end = 0
+        if self.training:
+            if self.freqm:
+                p.fmask_start, p.fmask_end = _draw_mask(self.freqm, self.n_mels)          # :81
+            if self.timem:
+                p.tmask_start, p.tmask_end = _draw_mask(self.timem, p.n_frames)           # :82
+        return ops.mel_frontend(x, self._window_padded, self._bin_mel, self._twiddle, p)
+
+    def extra_repr(self):
+        return 'winsize={}, hopsize={}'.format(self.win_length, self.hopsize)
+
+
+try:  # reference: ``model_ing = Ingredient("spectrograms")`` with AugmentMelSTFT as a command (:10,:18)
+    from ba3l.ingredients.ingredient import Ingredient  # type: ignore
+
+    model_ing = Ingredient("spectrograms")
+    AugmentMelSTFT = model_ing.command(AugmentMelSTFT)
+except Exception:
+    model_ing = None

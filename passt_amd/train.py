@@ -1,0 +1,75 @@
+"""The training step of the reference's caller, on the kernel path.
+
+Mirrors ``M.training_step`` (ex_audioset.py:155-198) + the optimizer step Lightning performs:
+waveform -> AugmentMelSTFT (:158) -> spectrogram mixup (:171-177, helpers/mixup.py) -> PaSST (:179)
+-> BCE-with-logits mean on the mixed targets (:181-186) -> backward -> gradient all-reduce (DDP) ->
+AdamW (:104-109) or SGD (model_speed_test, :392).  No autograd graph is built: forward/backward are
+explicit kernel sequences, parameters and gradients live in flat f32 buffers (one fused optimizer
+launch, per-block all-reduce buckets).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .ddp import GradReducer
+from .passt import passt_backward, passt_forward
+
+
+class TrainStep:
+    def __init__(self, net, mel=None, lr=2e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, optimizer="adamw",
+                 mixup_alpha=0.3, use_mixup=True, process_group=None):
+        self.net, self.mel = net, mel
+        self.lr, self.wd, self.betas, self.eps, self.optimizer = lr, weight_decay, betas, eps, optimizer
+        self.mixup_alpha, self.use_mixup = mixup_alpha, use_mixup
+        dev = next(net.parameters()).device
+        names = net._grad_names
+        self.named = [(n, p) for n, p in net.named_parameters() if n in names]
+        total = sum(p.numel() for _, p in self.named)
+        # flat parameter buffer: every nn.Parameter becomes a view (state_dict / load_state_dict keep working)
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grads, off = {}, 0
+        for n, p in self.named:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            self.grads[n] = self.flat_g[off:off + k].view(p.shape)
+            p.grad = self.grads[n]
+            off += k
+        self.m = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
+        self.v = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
+        self.reducer = GradReducer(self.flat_g, [(n, p.numel()) for n, p in self.named], len(net.blocks), process_group)
+        self.t = 0
+        net.mark_params_updated()
+
+    def step(self, wave_or_spec, target):
+        """wave (B,1,L) / (B,L) when a mel module was given, else a spectrogram (B,1,F,T).
+        Returns the loss as a 1-element device tensor (no host sync)."""
+        net = self.net
+        x = wave_or_spec
+        if self.mel is not None:
+            if x.dim() == 3:
+                x = x.reshape(-1, x.shape[2])                                   # mel_forward, :142-145
+            x = self.mel(x).unsqueeze(1)
+        y = target
+        if self.use_mixup:
+            B = x.shape[0]
+            perm = torch.randperm(B)                                            # helpers/mixup.py:6
+            lam = np.random.beta(self.mixup_alpha, self.mixup_alpha, B).astype(np.float32)
+            lam = np.maximum(lam, 1.0 - lam)
+            perm_d = perm.to(torch.int32).to(x.device, non_blocking=True)
+            lam_d = torch.from_numpy(lam).to(x.device, non_blocking=True)
+            x = ops.mixup(x, perm_d, lam_d)
+            y = ops.mixup(y, perm_d, lam_d)
+        logits, feat, ctx = passt_forward(net, x, save=True)
+        loss, dlogits = ops.bce_fwd_bwd(logits, y, grad_scale=1.0 / self.reducer.world)
+        passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self.reducer.on_block_done)
+        self.reducer.wait()
+        self.t += 1
+        if self.optimizer == "adamw":
+            ops.adamw(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.wd, self.t)
+        else:
+            ops.sgd(self.flat_p, self.flat_g, self.lr)
+        net.mark_params_updated()
+        return loss

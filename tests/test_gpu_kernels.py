@@ -1,0 +1,286 @@
+"""Per-kernel parity of libpasst_amd.so (through the C ABI) against plain torch fp32/fp64 references
+of the same op.  Tolerances: PA_F32 path ~1e-5..1e-4 relative (exact-f32 MFMA, different summation
+order); PA_BF16 path checked against a reference computed from the SAME bf16-rounded inputs, so only
+f32-accumulation order and the final bf16 rounding (2^-8 relative) remain.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from passt_amd import ops  # noqa: E402
+from passt_amd._lib import (EPI_DGELU, EPI_GELU, EPI_PARTIAL, EPI_RESID, EPI_STORE, PA_BF16,  # noqa: E402
+                            PA_F32)
+
+DEV = "cuda"
+TD = {PA_F32: torch.float32, PA_BF16: torch.bfloat16}
+_METRICS = {}
+
+
+def record(name, **kw):
+    _METRICS[name] = {k: float(v) for k, v in kw.items()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "kernel_parity_metrics.json"), "w") as f:
+        json.dump(_METRICS, f, indent=1, sort_keys=True)
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def tol(dt, f32=2e-5, bf16=1.2e-2):
+    return f32 if dt == PA_F32 else bf16
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 256), (474 * 2, 384, 128), (1000, 768, 768),
+                                   (77, 3072, 192)])
+def test_gemm_store_bias(dt, M, N, K):
+    A = rnd(M, K, seed=1).to(TD[dt]).to(DEV)
+    Bm = rnd(N, K, seed=2).to(TD[dt]).to(DEV)       # asymmetric random operands (transpose-detecting)
+    bias = rnd(N, seed=3).to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=TD[dt])
+    ops.gemm_nt(A, Bm, dt, EPI_STORE, bias=bias, out_lp=out)
+    ref = A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu()
+    e = rel_err(out, ref)
+    record(f"gemm_store[{dt},{M},{N},{K}]", rel=e)
+    assert e < tol(dt), e
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+def test_gemm_epilogues(dt):
+    M, N, K = 300, 264, 128
+    A = rnd(M, K, seed=4).to(TD[dt]).to(DEV)
+    Bm = rnd(N, K, seed=5, scale=0.3).to(TD[dt]).to(DEV)
+    bias = rnd(N, seed=6).to(DEV)
+    acc = A.double().cpu() @ Bm.double().cpu().T
+    # GELU: pre + exact-erf gelu of the stored pre
+    pre = torch.empty(M, N, device=DEV, dtype=TD[dt])
+    act = torch.empty(M, N, device=DEV, dtype=TD[dt])
+    ops.gemm_nt(A, Bm, dt, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
+    ref_pre = acc + bias.double().cpu()
+    assert rel_err(pre, ref_pre) < tol(dt)
+    ref_act = torch.nn.functional.gelu(pre.double().cpu())
+    e = rel_err(act, ref_act)
+    record(f"gemm_gelu[{dt}]", rel=e)
+    assert e < tol(dt, 2e-5, 6e-3)
+    # RESID plain
+    resid = rnd(M, N, seed=7).to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(A, Bm, dt, EPI_RESID, bias=bias, resid=resid, out_f32=out)
+    assert rel_err(out, ref_pre + resid.double().cpu()) < tol(dt, 2e-5, 3e-3)
+    # RESID with the patch-embed row remap
+    Np, Ntok, Bb = 100, 102, 3
+    table = rnd(Np, N, seed=8).to(DEV)
+    tok = torch.full((Bb, Ntok, N), 7.0, device=DEV)
+    ops.gemm_nt(A, Bm, dt, EPI_RESID, resid=table, out_f32=tok, row_mod=Np, out_batch_rows=Ntok, out_row_off=2)
+    ref_tok = torch.full((Bb, Ntok, N), 7.0, dtype=torch.float64)
+    ref_tok[:, 2:, :] = (acc.view(Bb, Np, N) + table.double().cpu())
+    assert rel_err(tok, ref_tok) < tol(dt, 2e-5, 3e-3)
+    # DGELU
+    aux = rnd(M, N, seed=9, scale=2.0).to(TD[dt]).to(DEV)
+    dg = torch.empty(M, N, device=DEV, dtype=TD[dt])
+    ops.gemm_nt(A, Bm, dt, EPI_DGELU, aux=aux, out_lp=dg)
+    a64 = aux.double().cpu()
+    gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+    e = rel_err(dg, acc * gp)
+    record(f"gemm_dgelu[{dt}]", rel=e)
+    assert e < tol(dt, 3e-5, 1.2e-2)
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+def test_wgrad_splitk_transpose_rowsum(dt):
+    """dW = dY^T X through transposes + split-K partials + ordered reduce; db through rowsum."""
+    M, N, K = 474 * 3 + 5, 384, 192
+    dY = rnd(M, N, seed=10).to(TD[dt]).to(DEV)
+    X = rnd(M, K, seed=11).to(TD[dt]).to(DEV)
+    Mp = ops.round_up(M, ops.kpad(dt))
+    dYt = ops.transpose(dY, dt, Mp)
+    Xt = ops.transpose(X, dt, Mp)
+    assert torch.equal(dYt[:, :M].float().cpu(), dY.float().cpu().T)
+    assert float(dYt[:, M:].float().abs().max()) == 0.0
+    dW = torch.full((N, K), 3.0, device=DEV)
+    ops.wgrad(dYt, Xt, dW, dt, accumulate=False)
+    ref = dY.double().cpu().T @ X.double().cpu()
+    e = rel_err(dW, ref)
+    record(f"wgrad[{dt}]", rel=e)
+    assert e < tol(dt, 3e-5, 1e-4)   # bf16 x bf16 products are exact in f32; only f32 accumulation differs
+    ops.wgrad(dYt, Xt, dW, dt, accumulate=True)
+    assert rel_err(dW, 2 * ref) < 1e-4
+    db = torch.empty(N, device=DEV)
+    ops.rowsum(dYt, db, ncols=M)
+    assert rel_err(db, dY.double().cpu().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("M,D", [(37, 128), (1000, 768), (130, 1024), (64, 192)])
+def test_layernorm(dt, M, D):
+    x = rnd(M, D, seed=12, scale=3.0).to(DEV) + 0.5
+    g = (rnd(D, seed=13) * 0.3 + 1).to(DEV)
+    b = rnd(D, seed=14).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, dt)
+    xr = x.double().cpu().requires_grad_(True)
+    gr, br = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    e = rel_err(y, ref.detach())
+    assert e < tol(dt, 1e-5, 6e-3), e
+    assert rel_err(mean, xr.detach().mean(1)) < 1e-5
+    dy = rnd(M, D, seed=15).to(TD[dt]).to(DEV)
+    dres = rnd(M, D, seed=16).to(DEV)
+    ref.backward(dy.double().cpu())
+    dg = torch.empty(D, device=DEV)
+    db = torch.empty(D, device=DEV)
+    dx, dx_lp = ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dg, db, True)
+    e1 = rel_err(dx, xr.grad + dres.double().cpu())
+    e2, e3 = rel_err(dg, gr.grad), rel_err(db, br.grad)
+    record(f"layernorm[{dt},{M},{D}]", fwd=e, dx=e1, dgamma=e2, dbeta=e3)
+    assert e1 < 2e-5 and e2 < 2e-5 and e3 < 2e-5, (e1, e2, e3)
+    assert rel_err(dx_lp, dx) < tol(dt, 1e-7, 5e-3)
+
+
+def _attn_ref(qkv, B, H, N, scale, d_o=None):
+    D = H * 64
+    t = qkv.double().cpu().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    q, k, v = t[0], t[1], t[2]
+    att = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(B * N, D)
+    lse = torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)        # (B,H,N)
+    dqkv = None
+    if d_o is not None:
+        o.backward(d_o.double().cpu())
+        dqkv = t.grad.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * D)
+    return o.detach(), lse.detach(), dqkv
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("B,H,N", [(2, 2, 67), (1, 3, 474), (2, 12, 130), (1, 2, 1190), (3, 2, 64)])
+def test_attention_fwd_bwd(dt, B, H, N):
+    D = H * 64
+    qkv = rnd(B * N, 3 * D, seed=17, scale=1.5).to(TD[dt]).to(DEV)
+    # spike one key against one query so the online-softmax max jumps mid-sequence (guide rule 26)
+    if N > 70:
+        qkv[N - 3, 0:64] *= 4.0
+        qkv[69, D:D + 64] = qkv[N - 3, 0:64]
+    scale = 0.125
+    o, lse = ops.attention_fwd(qkv, B, H, N, scale)
+    d_o = rnd(B * N, D, seed=18).to(TD[dt]).to(DEV)
+    ro, rlse, rdqkv = _attn_ref(qkv, B, H, N, scale, d_o)
+    e_o = rel_err(o, ro)
+    e_l = float((lse.double().cpu().view(B, H, N) - rlse).abs().max())
+    assert e_o < tol(dt, 2e-5, 1.5e-2), e_o
+    assert e_l < tol(dt, 2e-5, 2e-2), e_l
+    dqkv = ops.attention_bwd(qkv, o, d_o, lse, B, H, N, scale)
+    Dq = dqkv.double().cpu()
+    e_q, e_k, e_v = (rel_err(Dq[:, :D], rdqkv[:, :D]), rel_err(Dq[:, D:2 * D], rdqkv[:, D:2 * D]),
+                     rel_err(Dq[:, 2 * D:], rdqkv[:, 2 * D:]))
+    record(f"attention[{dt},{B},{H},{N}]", o=e_o, lse=e_l, dq=e_q, dk=e_k, dv=e_v)
+    lim = tol(dt, 5e-5, 4e-2)
+    assert e_q < lim and e_k < lim and e_v < lim, (e_q, e_k, e_v)
+
+
+def test_patch_ops_and_head():
+    import torch.nn.functional as Fnn
+    torch.manual_seed(3)
+    B, F, T, D, P, fs, ts = 3, 128, 250, 128, 16, 10, 10
+    Fd, Td, Tpe = 12, 24, 25
+    x = rnd(B, 1, F, T, seed=19).to(DEV)
+    pf = torch.tensor([0, 0, 3, 5, 11, 11], dtype=torch.int32, device=DEV)
+    pt = torch.tensor([1, 7, 0, 23, 2, 22], dtype=torch.int32, device=DEV)
+    Np = 6
+    for dt in (PA_F32, PA_BF16):
+        cols = ops.patch_gather(x, pf, pt, P, fs, ts, dt)
+        unf = Fnn.unfold(x.cpu(), (P, P), stride=(fs, ts)).view(B, P * P, Fd, Td)
+        ref = torch.stack([unf[:, :, int(f), int(t)] for f, t in zip(pf.cpu(), pt.cpu())], 1).reshape(B * Np, P * P)
+        assert rel_err(cols, ref) < tol(dt, 1e-7, 4e-3)
+    bias, tpe, fpe = rnd(D, seed=20).to(DEV), rnd(1, D, 1, Tpe, seed=21).to(DEV), rnd(1, D, Fd, 1, seed=22).to(DEV)
+    cls, dist, npe = rnd(1, 1, D, seed=23).to(DEV), rnd(1, 1, D, seed=24).to(DEV), rnd(1, 2, D, seed=25).to(DEV)
+    tok = torch.zeros(B, Np + 2, D, device=DEV)
+    toff = 1
+    table = ops.patch_pos_table(bias, tpe, fpe, pf, pt, toff, cls, dist, npe, tok)
+    ref_t = torch.stack([bias.cpu() + tpe.cpu()[0, :, 0, toff + int(t)] + fpe.cpu()[0, :, int(f), 0]
+                         for f, t in zip(pf.cpu(), pt.cpu())])
+    assert rel_err(table, ref_t) < 1e-6
+    assert rel_err(tok[:, 0], (cls + npe[:, :1]).cpu().expand(B, 1, D)[:, 0]) < 1e-6
+    assert rel_err(tok[:, 1], (dist + npe[:, 1:]).cpu().expand(B, 1, D)[:, 0]) < 1e-6
+    # backward reductions
+    dtok = rnd(B, Np + 2, D, seed=26).to(DEV)
+    g = {k: torch.full(s, 5.0, device=DEV) for k, s in dict(cls=(1, 1, D), dist=(1, 1, D), npe=(1, 2, D), b=(D,),
+                                                            t=(1, D, 1, Tpe), f=(1, D, Fd, 1)).items()}
+    dpatch = ops.patch_bwd(dtok, pf, pt, toff, Tpe, Fd, g["cls"], g["dist"], g["npe"], g["b"], g["t"], g["f"], PA_F32)
+    dc = dtok.cpu().double()
+    assert rel_err(g["cls"].view(-1), dc[:, 0].sum(0)) < 1e-5
+    assert rel_err(g["npe"].view(2, D)[1], dc[:, 1].sum(0)) < 1e-5
+    assert rel_err(g["b"], dc[:, 2:].sum((0, 1))) < 1e-5
+    rt = torch.zeros(D, Tpe, dtype=torch.float64)
+    rf = torch.zeros(D, Fd, dtype=torch.float64)
+    for p_, (f, t) in enumerate(zip(pf.cpu(), pt.cpu())):
+        rt[:, toff + int(t)] += dc[:, 2 + p_].sum(0)
+        rf[:, int(f)] += dc[:, 2 + p_].sum(0)
+    assert rel_err(g["t"].view(D, Tpe), rt) < 1e-5 and rel_err(g["f"].view(D, Fd), rf) < 1e-5
+    assert rel_err(dpatch, dc[:, 2:].reshape(B * Np, D)) < 1e-6
+    # head
+    Ntok, C = 9, 37
+    xx = rnd(B, Ntok, D, seed=27, scale=2.0).to(DEV)
+    ng, nb = (rnd(D, seed=28) * 0.3 + 1).to(DEV), rnd(D, seed=29).to(DEV)
+    hg, hb = (rnd(D, seed=30) * 0.3 + 1).to(DEV), rnd(D, seed=31).to(DEV)
+    W, bb = rnd(C, D, seed=32, scale=0.2).to(DEV), rnd(C, seed=33).to(DEV)
+    feat, hn, stats = ops.head_pre_fwd(xx, ng, nb, 1e-6, hg, hb, 1e-5)
+    logits = ops.linear_f32_fwd(hn, W, bb)
+    leaf = [t.double().cpu().requires_grad_(True) for t in (xx, ng, nb, hg, hb, W, bb)]
+    xn = Fnn.layer_norm(leaf[0], (D,), leaf[1], leaf[2], 1e-6)
+    rfeat = (xn[:, 0] + xn[:, 1]) / 2
+    rlog = Fnn.linear(Fnn.layer_norm(rfeat, (D,), leaf[3], leaf[4], 1e-5), leaf[5], leaf[6])
+    assert rel_err(feat, rfeat.detach()) < 1e-5 and rel_err(logits, rlog.detach()) < 1e-5
+    y = (rnd(B, C, seed=34) > 0.7).float().to(DEV)
+    loss, dlog = ops.bce_fwd_bwd(logits, y)
+    rloss = Fnn.binary_cross_entropy_with_logits(rlog, y.double().cpu(), reduction="none").mean()
+    dfeat_extra = rnd(B, D, seed=35).to(DEV)
+    (rloss + (rfeat * dfeat_extra.double().cpu()).sum()).backward()
+    assert abs(float(loss) - float(rloss)) < 1e-6
+    dW, dbb = torch.empty_like(W), torch.empty_like(bb)
+    dhn = ops.linear_f32_bwd(dlog, hn, W, dW, dbb)
+    dx, part = ops.head_pre_bwd(dhn, dfeat_extra, xx, feat, ng, hg, stats)
+    assert rel_err(dW, leaf[5].grad) < 1e-5 and rel_err(dbb, leaf[6].grad) < 1e-5
+    assert rel_err(dx, leaf[0].grad) < 2e-5
+    sums = torch.empty(4, D, device=DEV)
+    for j in range(4):
+        ops.colsum_f32(part.view(B, 4, D)[:, j, :], sums[j])
+    for j, idx in enumerate((3, 4, 1, 2)):
+        assert rel_err(sums[j], leaf[idx].grad) < 2e-5, j
+
+
+def test_mixup_and_optimizers():
+    B = 5
+    x = rnd(B, 1, 16, 40, seed=36).to(DEV)
+    perm = torch.tensor([3, 0, 4, 1, 2], dtype=torch.int32, device=DEV)
+    lam = torch.tensor([0.9, 0.5, 0.7, 1.0, 0.6], device=DEV)
+    out = ops.mixup(x, perm, lam)
+    xc, lc = x.cpu(), lam.cpu().view(B, 1, 1, 1)
+    assert rel_err(out, xc * lc + xc[perm.cpu().long()] * (1 - lc)) < 1e-6
+    n = 10007
+    p0, g = rnd(n, seed=37), rnd(n, seed=38)
+    pr = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([pr], lr=2e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        pr.grad = (g * step).double()
+        opt.step()
+        ops.adamw(p, (g * step).to(DEV), m, v, 2e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+    assert rel_err(p, pr.detach()) < 1e-5
+    q = p0.clone().to(DEV)
+    ops.sgd(q, g.to(DEV), 0.1)
+    assert rel_err(q, p0 - 0.1 * g) < 1e-6
