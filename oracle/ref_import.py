@@ -106,6 +106,11 @@ def load_reference():
         if m is not None:
             sys.modules[k] = m
     sys.path.remove(REFERENCE_ROOT)
+    # the stubs stay referenced by the reference modules; drop them from sys.modules so that other
+    # libraries probing e.g. importlib.util.find_spec("torchaudio") do not trip over them
+    for k in [k for k in sys.modules if k.split(".")[0] in ("timm", "ba3l", "torchaudio")]:
+        if getattr(sys.modules[k], "__spec__", None) is None:
+            del sys.modules[k]
     _loaded["passt"], _loaded["pre"] = ref_passt, ref_pre
     return ref_passt, ref_pre
 

@@ -20,6 +20,17 @@ __global__ void mixup_kernel(const float* __restrict__ x, const int32_t* __restr
     }
 }
 
+__global__ void mixup_scalar_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm, const float* __restrict__ lam,
+                                    float* __restrict__ out, int64_t per) {
+    const int b = blockIdx.y;
+    const float l = lam[b];
+    const float* xa = x + (int64_t)b * per;
+    const float* xb = x + (int64_t)perm[b] * per;
+    float* o = out + (int64_t)b * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = xa[i] * l + xb[i] * (1.f - l);
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -45,7 +56,11 @@ using namespace pa;
 
 extern "C" int pa_mixup(const float* x, const int32_t* perm, const float* lam, float* out, int B, int64_t per_sample, void* stream) {
     if (!x || !perm || !lam || !out || B <= 0 || per_sample <= 0) return PA_EINVAL;
-    if (per_sample % 4) return PA_EUNSUPPORTED;
+    if (per_sample % 4) {   // e.g. the (B, 527) target matrix: scalar path
+        dim3 grid((unsigned)std::min<int64_t>(cdiv(per_sample, 256), 64), (unsigned)B);
+        hipLaunchKernelGGL(mixup_scalar_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, perm, lam, out, per_sample);
+        return check_launch();
+    }
     const int64_t per4 = per_sample / 4;
     dim3 grid((unsigned)std::min<int64_t>(cdiv(per4, 256), 64), (unsigned)B);
     hipLaunchKernelGGL(mixup_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, perm, lam, out, per4);

@@ -1,0 +1,153 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads without a GPU, exports every
+symbol include/passt_amd.h declares, the ctypes structs match the C layout, and the product path
+refuses to run without a HIP device (no silent fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "passt_amd.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from passt_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
+        assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.pa_abi_version() == 1
+    assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
+    assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
+    assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 512 * 2 * 768
+
+
+def test_ctypes_structs_match_the_c_layout():
+    from passt_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "passt_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
+         offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
+         offsetof(pa_gemm_args, split_k), sizeof(pa_mel_params));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    G = _lib.GemmArgs
+    got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
+           G.split_k.offset, ctypes.sizeof(_lib.MelParams)]
+    assert got == [int(v) for v in out]
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    from passt_amd import _lib
+    lib = _lib.load()
+    a = _lib.GemmArgs()
+    assert lib.pa_gemm_nt(ctypes.byref(a), None) == -1                        # null operands
+    assert lib.pa_layernorm_fwd(None, None, None, None, 0, None, None, 4, 4, 1e-6, None) == -1
+    p = _lib.MelParams()
+    assert lib.pa_mel_frontend_fwd(None, 1, 100, None, None, None, None, ctypes.byref(p), None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import passt_amd
+    from passt_amd._lib import PasstAmdError
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = passt_amd.PaSST(img_size=(128, 100), stride=10, embed_dim=128, depth=1, num_heads=2, num_classes=5,
+                            distilled=True)
+    with pytest.raises(PasstAmdError):
+        m(torch.zeros(1, 1, 128, 100))
+    mel = passt_amd.AugmentMelSTFT(fmax=15000)
+    with pytest.raises(PasstAmdError):
+        mel(torch.zeros(1, 32000))
+    # and nothing in the product imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "passt_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(root, f)).read().replace("# oracle", ""), f
+
+
+def test_state_dict_schema_and_parameter_order():
+    import passt_amd
+    from oracle import detgen
+    from oracle import passt_oracle as O
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = passt_amd.get_model(arch="passt_s_swa_p16_128_ap476", pretrained=False, n_classes=527)
+    sd = m.state_dict()
+    want = detgen.passt_state_dict(O.make_cfg(), 0)
+    assert list(sd.keys()) == list(want.keys()) or sorted(sd.keys()) == sorted(want.keys())
+    for k, v in want.items():
+        assert tuple(sd[k].shape) == v.shape, k
+    assert sum(p.numel() for p in m.parameters()) == 86153758
+    names = [n for n, _ in m.named_parameters()]
+    assert names[:5] == ["cls_token", "dist_token", "new_pos_embed", "freq_new_pos_embed", "time_new_pos_embed"]
+    assert names[-2:] == ["head_dist.weight", "head_dist.bias"]
+    from oracle import ref_import
+    if ref_import.reference_available():
+        ref = ref_import.build_reference_passt(O.make_cfg(embed_dim=128, depth=2, num_heads=2, num_classes=9,
+                                                          img_size=(128, 100)),
+                                               detgen.passt_state_dict(O.make_cfg(embed_dim=128, depth=2, num_heads=2,
+                                                                                  num_classes=9, img_size=(128, 100)), 1))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mine = passt_amd.PaSST(img_size=(128, 100), stride=10, embed_dim=128, depth=2, num_heads=2, num_classes=9,
+                                   distilled=True)
+        assert [n for n, _ in ref.named_parameters()] == [n for n, _ in mine.named_parameters()]
+        mine.load_state_dict(ref.state_dict(), strict=True)
+
+
+def test_host_index_logic_matches_reference_order():
+    """passt_amd's kept-patch enumeration == the reference's embed-then-index order (oracle semantics)."""
+    import passt_amd
+    from passt_amd.passt import draw_patchout, kept_patches
+    from oracle import passt_oracle as O
+    for (st, sf, u, T) in ((6, 3, 5, 250), (0, 2, 0, 250), (4, 0, 9, 180), (0, 0, 0, 250)):
+        cfg = O.make_cfg(embed_dim=128, depth=1, num_heads=2, num_classes=3, img_size=(128, 250), stride=(10, 10),
+                         s_patchout_t=st, s_patchout_f=sf, u_patchout=u)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = passt_amd.PaSST(u_patchout=u, s_patchout_t=st, s_patchout_f=sf, img_size=(128, 250), stride=10,
+                                embed_dim=128, depth=1, num_heads=2, num_classes=3, distilled=True).train()
+        Fd, Td = 12, (T - 16) // 10 + 1
+        torch.manual_seed(42)
+        d = O.draw_patchout(cfg, Fd, Td, True)
+        torch.manual_seed(42)
+        toff, T_eff, it, if_, iu = draw_patchout(m, Fd, Td)
+        assert toff == d["toff"] and T_eff == d["T_eff"]
+        # reference order on a grid of (f, t) labels
+        grid_f = torch.arange(Fd).view(Fd, 1).expand(Fd, T_eff)
+        grid_t = torch.arange(T_eff).view(1, T_eff).expand(Fd, T_eff)
+        gf, gt = grid_f, grid_t
+        if d["idx_t"] is not None:
+            gf, gt = gf[:, d["idx_t"]], gt[:, d["idx_t"]]
+        if d["idx_f"] is not None:
+            gf, gt = gf[d["idx_f"], :], gt[d["idx_f"], :]
+        gf, gt = gf.reshape(-1), gt.reshape(-1)
+        if d["idx_u"] is not None:
+            gf, gt = gf[d["idx_u"]], gt[d["idx_u"]]
+        pf, pt = kept_patches(Fd, T_eff, it, if_, iu)
+        assert np.array_equal(pf, gf.numpy()) and np.array_equal(pt, gt.numpy())

@@ -1,0 +1,80 @@
+"""world_size-2 test of the data-parallel gradient reducer on CPU (gloo): bucket layout follows the
+backward's completion order, every bucket is all-reduced exactly once, the result equals the sum over
+ranks, and parameters that never get a gradient (head_dist.*) are not in the buffer."""
+import os
+import socket
+import warnings
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from passt_amd.ddp import GradReducer, bucket_layout
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_model():
+    import passt_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return passt_amd.PaSST(img_size=(128, 100), stride=10, embed_dim=128, depth=3, num_heads=2, num_classes=7,
+                               distilled=True)
+
+
+def test_bucket_layout_partitions_the_flat_buffer():
+    m = _small_model()
+    names = m._grad_names
+    sizes = [(n, p.numel()) for n, p in m.named_parameters() if n in names]
+    assert not any(n.startswith("head_dist") for n, _ in sizes)
+    spans = bucket_layout(sizes, 3)
+    assert sorted(spans) == [-1, 0, 1, 2, 3]
+    order = [-1, 0, 1, 2, 3]
+    pos = 0
+    for b in order:
+        s, e = spans[b]
+        assert s == pos and e > s
+        pos = e
+    assert pos == sum(n for _, n in sizes) == m._n_grad_elems
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _small_model()
+    names = m._grad_names
+    sizes = [(n, p.numel()) for n, p in m.named_parameters() if n in names]
+    total = sum(n for _, n in sizes)
+    flat = torch.arange(total, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(flat, sizes, 3)
+    seen = []
+    for blk in (3, 2, 1, 0, -1):          # the order passt_backward reports completion
+        red.on_block_done(blk)
+        seen.append(len(red.pending))
+    red.wait()
+    expect = torch.arange(total, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    q.put((rank, bool(torch.equal(flat, expect)), seen, red.world))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, seen, w in res:
+        assert ok, f"rank {rank}: reduced gradients differ from the sum over ranks"
+        assert seen == [1, 2, 3, 4, 5] and w == 2

@@ -249,7 +249,7 @@ def test_patch_ops_and_head():
     rloss = Fnn.binary_cross_entropy_with_logits(rlog, y.double().cpu(), reduction="none").mean()
     dfeat_extra = rnd(B, D, seed=35).to(DEV)
     (rloss + (rfeat * dfeat_extra.double().cpu()).sum()).backward()
-    assert abs(float(loss) - float(rloss)) < 1e-6
+    assert abs(float(loss) - float(rloss.detach())) < 1e-6
     dW, dbb = torch.empty_like(W), torch.empty_like(bb)
     dhn = ops.linear_f32_bwd(dlog, hn, W, dW, dbb)
     dx, part = ops.head_pre_bwd(dhn, dfeat_extra, xx, feat, ng, hg, stats)
@@ -270,6 +270,9 @@ def test_mixup_and_optimizers():
     out = ops.mixup(x, perm, lam)
     xc, lc = x.cpu(), lam.cpu().view(B, 1, 1, 1)
     assert rel_err(out, xc * lc + xc[perm.cpu().long()] * (1 - lc)) < 1e-6
+    y = rnd(B, 527, seed=39).to(DEV)                       # row length not a multiple of 4
+    yc = y.cpu()
+    assert rel_err(ops.mixup(y, perm, lam), yc * lam.cpu().view(B, 1) + yc[perm.cpu().long()] * (1 - lam.cpu().view(B, 1))) < 1e-6
     n = 10007
     p0, g = rnd(n, seed=37), rnd(n, seed=38)
     pr = torch.nn.Parameter(p0.clone().double())
