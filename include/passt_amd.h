@@ -139,11 +139,20 @@ typedef struct {
     int32_t split_k;       /* PA_EPI_PARTIAL: number of K slices (grid.z); else must be 1 */
 } pa_gemm_args;
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
+/* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major
+ * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over
+ * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic). */
+int pa_gemm_tn(const pa_gemm_args* a, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_z partial[z][i], i < n */
 int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out, int accumulate,
                        void* stream);
 /* out[r] = (accumulate ? out[r] : 0) + sum_c in[r][c], c < C  (bias gradients from dY^T) */
 int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate,
+              void* stream);
+/* out[c] = (accumulate ? out[c] : 0) + sum_r in[r][c] for a tall [R][C] matrix of `dtype` (bias gradients
+ * straight from dY); ws: f32 workspace of pa_colsum_ws_floats(R, C) elements. */
+int64_t pa_colsum_ws_floats(int R, int C);
+int pa_colsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate, float* ws,
               void* stream);
 /* out[c] = (accumulate ? out[c] : 0) + sum_r in[r][c]  -- f32 in, small R (head/LN partials) */
 int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate, void* stream);

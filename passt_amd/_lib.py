@@ -43,6 +43,9 @@ SIGNATURES = {
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
     "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
+    "pa_colsum_ws_floats": (i64, [i32, i32]),
+    "pa_colsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp]),
     "pa_reduce_partials": (i32, [vp, i32, i64, vp, i32, vp]),
     "pa_rowsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "pa_colsum_f32": (i32, [vp, i32, i32, i32, vp, i32, vp]),

@@ -63,6 +63,75 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v
     }
 }
 
+// Shared epilogue: the 2x2 MFMA accumulators of this wave (64x64 outputs at rows m0 + wr*64, columns
+// n0 + wc*64) -> per-wave LDS slab -> 8-wide row vectors with the fused epilogue math.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[2][2], char* smem, int m0,
+                                              int n0, int wave, int wr, int wc, int lane) {
+    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused below
+    float* slab = (float*)smem + wave * (32 * 68);
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int ncol = n0 + wc * 64 + ecol;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if constexpr (EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU) {
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = (ncol + e < a.N) ? a.bias[ncol + e] : 0.f;
+        }
+    }
+    const bool full_n = ncol + 8 <= a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[acc_row(r, lane) * 68 + j * 32 + (lane & 31)] = acc[i][j][r];
+        // same-wave LDS RAW: the LDS queue is in order per wave; no barrier needed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + erow;
+            const int m = m0 + wr * 64 + i * 32 + row;
+            const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
+            const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
+            if (m >= a.M || ncol >= a.N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias8[e]; v[4 + e] = hi[e] + bias8[4 + e]; }
+            if constexpr (EPI == PA_EPI_STORE) {
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_GELU) {
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[e])));
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+                store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_RESID) {
+                int64_t rrow = m, orow = m;
+                if (a.row_mod > 0) {
+                    rrow = m % a.row_mod;
+                    orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + rrow;
+                }
+                float rs[8];
+                load8<float>(a.resid + rrow * a.ldr + ncol, rs, full_n ? 8 : a.N - ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rs[e];
+                store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v, full_n ? 8 : a.N - ncol);
+            } else if constexpr (EPI == PA_EPI_DGELU) {
+                float pre[8];
+                load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, pre, full_n ? 8 : a.N - ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(pre[e]);
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+            } else {  // PA_EPI_PARTIAL
+                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v,
+                              full_n ? 8 : a.N - ncol);
+            }
+        }
+    }
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_n,
                                                       const int nwg, const int ksteps_per_split) {
@@ -146,69 +215,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, cons
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (per-wave [32][68] f32 slab) -> 8-wide row vectors -------
-    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused below
-    float* slab = (float*)smem + wave * (32 * 68);
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    const int ncol = n0 + wc * 64 + ecol;
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if constexpr (EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU) {
-        if (a.bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = (ncol + e < a.N) ? a.bias[ncol + e] : 0.f;
-        }
-    }
-    const bool full_n = ncol + 8 <= a.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab[acc_row(r, lane) * 68 + j * 32 + (lane & 31)] = acc[i][j][r];
-        // same-wave LDS RAW: the LDS queue is in order per wave; no barrier needed
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + erow;
-            const int m = m0 + wr * 64 + i * 32 + row;
-            const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
-            const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
-            if (m >= a.M || ncol >= a.N) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias8[e]; v[4 + e] = hi[e] + bias8[4 + e]; }
-            if constexpr (EPI == PA_EPI_STORE) {
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
-            } else if constexpr (EPI == PA_EPI_GELU) {
-                float g[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[e])));
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
-                store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g, full_n ? 8 : a.N - ncol);
-            } else if constexpr (EPI == PA_EPI_RESID) {
-                int64_t rrow = m, orow = m;
-                if (a.row_mod > 0) {
-                    rrow = m % a.row_mod;
-                    orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + rrow;
-                }
-                float rs[8];
-                load8<float>(a.resid + rrow * a.ldr + ncol, rs, full_n ? 8 : a.N - ncol);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rs[e];
-                store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v, full_n ? 8 : a.N - ncol);
-            } else if constexpr (EPI == PA_EPI_DGELU) {
-                float pre[8];
-                load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, pre, full_n ? 8 : a.N - ncol);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(pre[e]);
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
-            } else {  // PA_EPI_PARTIAL
-                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v,
-                              full_n ? 8 : a.N - ncol);
-            }
-        }
-    }
+    gemm_epilogue<T, EPI>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
 template <typename T, int EPI>
@@ -226,6 +233,198 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(nwg, splits), dim3(256), GEMM_LDS, st, a,
                        tiles_n, nwg, per);
     return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN GEMM for weight gradients:  C[N][K] = sum_m A[m][N]^T B[m][K]  (A = dY, B = X, both token-major,
+// read IN PLACE -- no transposed copies).  The reduction index m runs down LDS tile ROWS, so both MFMA
+// operands are column fragments: ds_read_b64_tr_b16 (bf16) / ds_read_b32 (f32).  Tiles are
+// [MROWS tokens][128 columns], 16 KiB per operand per stage, global_load_lds double buffered; bf16 rows
+// (256 B = one full bank line) are XOR-swizzled by (row&3) so the 4 rows of a transpose read hit 4
+// different 64-byte bank quarters.  Split-K over tokens writes f32 partial slabs (EPI_PARTIAL).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct TNGeom {
+    static constexpr int COLS = 128;
+    static constexpr int ROWB = COLS * (int)sizeof(T);     // 256 / 512
+    static constexpr int MROWS = TILE_BYTES / ROWB;        // 64 / 32 tokens per stage
+    static constexpr int RPI = 1024 / ROWB;                // tile rows filled per wave-instruction: 4 / 2
+    static constexpr int LPR = ROWB / 16;                  // lanes (16-byte chunks) per row: 16 / 32
+    static constexpr int EPC = 16 / (int)sizeof(T);
+    static constexpr int FSTEP = Frag<T>::K;               // tokens per fragment step: 16 / 8
+};
+
+template <typename T> __device__ __forceinline__ int tn_swz(int row, int c) {
+    if constexpr (sizeof(T) == 2) return row * 256 + ((c ^ ((row & 3) << 2)) << 4);
+    else return row * 512 + (c << 4);
+}
+
+// column fragment for tokens [ms*FSTEP, +FSTEP) at columns cbase + (lane&31)
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type tn_frag(const char* tile, int ms, int cbase, int lane);
+template <>
+__device__ __forceinline__ bf16x8 tn_frag<bf16>(const char* tile, int ms, int cbase, int lane) {
+    const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int r1 = ms * 16 + h * 8 + (p >> 2);
+    const int col = cbase + g * 16 + (p & 3) * 4;
+    const int within = (col & 7) * 2;
+    const bf16x4 lo = lds_tr16(tile + tn_swz<bf16>(r1, col >> 3) + within);
+    const bf16x4 hi = lds_tr16(tile + tn_swz<bf16>(r1 + 4, col >> 3) + within);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+template <>
+__device__ __forceinline__ f32x4 tn_frag<float>(const char* tile, int ms, int cbase, int lane) {
+    const int col = cbase + (lane & 31), h = lane >> 5;
+    f32x4 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = *(const float*)(tile + (ms * 8 + h * 4 + e) * 512 + col * 4);
+    return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
+                                                      const int steps_per_split) {
+    using G = TNGeom<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bid = xcd_swizzle(blockIdx.x, nwg);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;   // output rows (A columns) / output cols (B columns)
+    const int Mtok = a.K;
+    const int steps_total = (Mtok + G::MROWS - 1) / G::MROWS;
+    const int st_begin = blockIdx.y * steps_per_split;
+    const int st_end = min(steps_total, st_begin + steps_per_split);
+    const int nsteps = st_end - st_begin;
+
+    // per-lane sources of this wave's 4 + 4 copies per stage
+    const char* srcA[4];
+    const char* srcB[4];
+    int rowin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;
+        const int row = q * G::RPI + lane / G::LPR;
+        const int pc = lane % G::LPR;
+        const int c = sizeof(T) == 2 ? (pc ^ ((row & 3) << 2)) : pc;
+        rowin[i] = row;
+        // column chunks beyond the matrix are clamped (their outputs are never stored)
+        const int ca = min(m0 + c * G::EPC, a.M - G::EPC), cb = min(n0 + c * G::EPC, a.N - G::EPC);
+        srcA[i] = (const char*)a.A + (int64_t)ca * sizeof(T);
+        srcB[i] = (const char*)a.B + (int64_t)cb * sizeof(T);
+    }
+    auto stage = [&](int buf, int step) {
+        char* sA = smem + buf * (2 * TILE_BYTES) + wave * 4096;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t tok = min((int64_t)(st_begin + step) * G::MROWS + rowin[i], (int64_t)Mtok - 1);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(srcA[i] + tok * a.lda * sizeof(T)),
+                (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(srcB[i] + tok * a.ldb * sizeof(T)),
+                (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+        }
+    };
+    // rows of the LAST stage beyond Mtok were filled with a clamped (duplicate) token: zero them, each wave
+    // the rows it staged itself, after its copies landed and before the barrier
+    auto zero_tail = [&](int buf, int step) {
+        const int valid = Mtok - (st_begin + step) * G::MROWS;      // valid rows in this stage
+        if (valid >= G::MROWS) return;
+        char* sA = smem + buf * (2 * TILE_BYTES);
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (rowin[i] >= valid) {
+                const int off = (wave * 4 + i) * 1024 + lane * 16;
+                *(uint4*)(sA + off) = make_uint4(0, 0, 0, 0);
+                *(uint4*)(sB + off) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nsteps > 0) stage(0, 0);
+    for (int t = 0; t < nsteps; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        zero_tail(t & 1, t);
+        __syncthreads();
+        if (t + 1 < nsteps) stage((t + 1) & 1, t + 1);
+        const char* sA = smem + (t & 1) * (2 * TILE_BYTES);
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ms = 0; ms < G::MROWS / G::FSTEP; ++ms) {
+            typename Frag<T>::type fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = tn_frag<T>(sA, ms, wr * 64 + i * 32, lane);
+                fb[i] = tn_frag<T>(sB, ms, wc * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+        }
+    }
+    gemm_epilogue<T, PA_EPI_PARTIAL>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+}
+
+template <typename T>
+static int launch_gemm_tn(const pa_gemm_args& a, hipStream_t st) {
+    const int tiles_m = (int)cdiv(a.M, BM), tiles_n = (int)cdiv(a.N, BN);
+    const int nwg = tiles_m * tiles_n;
+    const int steps = (int)cdiv(a.K, TNGeom<T>::MROWS);
+    const int per = (int)cdiv(steps, a.split_k);
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GEMM_LDS) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(nwg, a.split_k), dim3(256), GEMM_LDS, st, a, tiles_n, nwg, per);
+    return check_launch();
+}
+
+// ---- column sums of a [R][C] matrix (bias gradients): stage 1 = per-(row block, 64-column tile) partials
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict__ in, int R, int C, int ld,
+                                                            float* __restrict__ part, int rows_per_block) {
+    __shared__ float red[32][65];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;           // 8 threads x 8 columns, 32 rows per pass
+    const int c0 = blockIdx.x * 64 + tx * 8;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const bool full = c0 + 8 <= C;
+    for (int r = r_begin + ty; r < r_end; r += 32) {
+        float v[8];
+        if (c0 < C) {
+            load8<T>(in + (int64_t)r * ld + c0, v, full ? 8 : C - c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < 32; ++y) t += red[y][threadIdx.x];
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < C) part[(int64_t)blockIdx.y * C + c] = t;
+    }
 }
 
 template <typename T>
@@ -373,5 +572,37 @@ extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, 
                              void* stream) {
     if (!in || !out || R <= 0 || C <= 0) return PA_EINVAL;
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out, accumulate);
+    return check_launch();
+}
+
+extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->out_f32 || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->split_k < 1) return PA_EINVAL;
+    if (a->epilogue != PA_EPI_PARTIAL) return PA_EUNSUPPORTED;
+    const size_t es = a->dtype == PA_BF16 ? 2 : 4;
+    if ((a->lda * es) % 16 || (a->ldb * es) % 16 || a->ldo32 % 4) return PA_EUNSUPPORTED;
+    if (a->M < (int)(16 / es) || a->N < (int)(16 / es)) return PA_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == PA_BF16) return launch_gemm_tn<bf16>(*a, st);
+    if (a->dtype == PA_F32) return launch_gemm_tn<float>(*a, st);
+    return PA_EINVAL;
+}
+
+extern "C" int64_t pa_colsum_ws_floats(int R, int C) { return (int64_t)std::min<int64_t>(64, cdiv(R, 256)) * C; }
+
+extern "C" int pa_colsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate, float* ws,
+                         void* stream) {
+    if (!in || !out || !ws || R <= 0 || C <= 0) return PA_EINVAL;
+    const size_t es = dtype == PA_BF16 ? 2 : 4;
+    if ((ld * es) % 16) return PA_EUNSUPPORTED;
+    const int rblocks = (int)std::min<int64_t>(64, cdiv(R, 256));
+    const int rpb = (int)cdiv(R, rblocks);
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)rblocks);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PA_BF16) hipLaunchKernelGGL(colsum_stage1_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)in, R, C, ld, ws, rpb);
+    else if (dtype == PA_F32) hipLaunchKernelGGL(colsum_stage1_kernel<float>, grid, dim3(256), 0, st, (const float*)in, R, C, ld, ws, rpb);
+    else return PA_EINVAL;
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, ws, rblocks, C, C, out, accumulate);
     return check_launch();
 }

@@ -9,7 +9,7 @@
 namespace pa {
 
 static constexpr int LN_MAXV = 8;       // float4 per lane -> D <= 2048 (kernels are instantiated for 1,2,3,4,8)
-static constexpr int LN_BWD_BLOCKS = 512;
+static constexpr int LN_BWD_BLOCKS = 1024;
 
 template <typename T> __device__ __forceinline__ void store4(T* p, const float4& v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float4& v) { *(float4*)p = v; }
@@ -144,20 +144,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// out[which][c] (+)= sum_b ws[b][which][c];  block = 64 columns x 4 row groups
+// out[which][c] (+)= sum_b ws[b][which][c];  block = 16 columns x 16 row groups (many small blocks:
+// the partials are only a few MB, parallelism matters more than coalescing width)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int accumulate) {
-    __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + cx;   // index into [2][D]
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + cx;   // index into [2][D]
     float s = 0.f;
     if (k < 2 * D)
-        for (int b = ry; b < nblk; b += 4) s += ws[(int64_t)b * 2 * D + k];
+        for (int b = ry; b < nblk; b += 16) s += ws[(int64_t)b * 2 * D + k];
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && k < 2 * D) {
-        s = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) s += red[y][cx];
         float* out = k < D ? dgamma + k : dbeta + (k - D);
         *out = (accumulate ? *out : 0.f) + s;
     }
@@ -210,6 +213,6 @@ extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const
 #undef PA_LN_BWD
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 64)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 16)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, accumulate);
     return check_launch();
 }

@@ -177,6 +177,47 @@ def wgrad(dY_t, X_t, out_f32, dtype, accumulate=False, partial_ws=None):
     return partial_ws
 
 
+def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
+    """out[N][K] (+)= dY[M][N]^T X[M][K], operands read in place (pa_gemm_tn), deterministic split-K."""
+    Mtok, N = dY.shape
+    K = X.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    mrows = 64 if dtype == PA_BF16 else 32
+    steps = (Mtok + mrows - 1) // mrows
+    S = pick_split_k(tiles, steps)
+    need = S * N * K
+    if partial_ws is None or partial_ws.numel() < need:
+        partial_ws = torch.empty(need, device=dY.device, dtype=torch.float32)
+    part = partial_ws[:need].view(S, N, K)
+    a = GemmArgs()
+    a.dtype, a.epilogue = dtype, EPI_PARTIAL
+    a.M, a.N, a.K = N, K, Mtok
+    a.lda, a.ldb = dY.stride(0), X.stride(0)
+    a.A, a.B = _p(dY), _p(X)
+    a.out_f32, a.ldo32 = _p(part), K
+    a.split_k = S
+    lib = _lib.load()
+    if GEMM_PROFILE is None:
+        check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
+    else:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
+        ev1.record()
+        GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, 2.0 * N * K * Mtok))
+    check(lib.pa_reduce_partials(_p(part), S, N * K, _p(out_f32), int(accumulate), _stream()), "pa_reduce_partials")
+    return partial_ws
+
+
+def colsum(x, out_f32, accumulate=False):
+    """out[C] (+)= column sums of the tall matrix x[R][C] (bf16 or f32)."""
+    R, Cc = x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.pa_colsum_ws_floats(R, Cc), device=x.device, dtype=torch.float32)
+    check(lib.pa_colsum(_p(x), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out_f32), int(accumulate), _p(ws),
+                        _stream()), "pa_colsum")
+
+
 def rowsum(x, out_f32, ncols=None, accumulate=False):
     R, Cc = x.shape
     check(_lib.load().pa_rowsum(_p(x), PA_DTYPE[x.dtype], R, Cc if ncols is None else ncols, x.stride(0),

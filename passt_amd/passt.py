@@ -235,21 +235,11 @@ def passt_forward(model, x, save):
 
 
 def _wgrad_pair(dY, X, dW, db, dt, scratch, accumulate):
-    """dW[N][K] = dY^T X, db[N] = colsum(dY) from row-major dY[M][N], X[M][K] (v1: transpose both
-    operands -- zero padded along M -- and run the NT GEMM with deterministic split-K)."""
-    Mrows = dY.shape[0]
-    Mp = ops.round_up(Mrows, ops.kpad(dt))
-    N, K = dY.shape[1], X.shape[1]
-    need_a, need_b = N * Mp, K * Mp
-    if scratch.get("a") is None or scratch["a"].numel() < need_a:
-        scratch["a"] = torch.empty(need_a, device=dY.device, dtype=ops.TORCH_DTYPE[dt])
-    if scratch.get("b") is None or scratch["b"].numel() < need_b:
-        scratch["b"] = torch.empty(need_b, device=dY.device, dtype=ops.TORCH_DTYPE[dt])
-    dYt = ops.transpose(dY, dt, Mp, out=scratch["a"][:need_a].view(N, Mp))
-    Xt = ops.transpose(X, dt, Mp, out=scratch["b"][:need_b].view(K, Mp))
-    scratch["part"] = ops.wgrad(dYt, Xt, dW, dt, accumulate, scratch.get("part"))
+    """dW[N][K] = dY^T X, db[N] = colsum(dY) from row-major dY[M][N], X[M][K], both read in place
+    (pa_gemm_tn: transpose-read MFMA operands, deterministic split-K over tokens)."""
+    scratch["part"] = ops.wgrad_tn(dY, X, dW.view(dY.shape[1], -1), dt, accumulate, scratch.get("part"))
     if db is not None:
-        ops.rowsum(dYt, db, ncols=Mrows, accumulate=accumulate)
+        ops.colsum(dY, db, accumulate=accumulate)
 
 
 def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):

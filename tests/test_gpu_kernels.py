@@ -126,6 +126,28 @@ def test_wgrad_splitk_transpose_rowsum(dt):
 
 
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("M,N,K", [(474 * 3 + 5, 384, 192), (64, 128, 128), (2000, 768, 256), (333, 136, 3072),
+                                   (30336 // 8, 2304, 768)])
+def test_wgrad_tn_in_place_and_colsum(dt, M, N, K):
+    """dW = dY^T X straight from the row-major operands (transpose-read MFMA fragments), ragged M/N tails."""
+    dY = rnd(M, N, seed=40).to(TD[dt]).to(DEV)
+    X = rnd(M, K, seed=41).to(TD[dt]).to(DEV)
+    dW = torch.full((N, K), 3.0, device=DEV)
+    ops.wgrad_tn(dY, X, dW, dt, accumulate=False)
+    ref = dY.double().cpu().T @ X.double().cpu()
+    e = rel_err(dW, ref)
+    record(f"wgrad_tn[{dt},{M},{N},{K}]", rel=e)
+    assert e < tol(dt, 3e-5, 1e-4), e
+    ops.wgrad_tn(dY, X, dW, dt, accumulate=True)
+    assert rel_err(dW, 2 * ref) < 1e-4
+    db = torch.full((N,), 9.0, device=DEV)
+    ops.colsum(dY, db)
+    assert rel_err(db, dY.double().cpu().sum(0)) < 1e-4
+    ops.colsum(dY, db, accumulate=True)
+    assert rel_err(db, 2 * dY.double().cpu().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
 @pytest.mark.parametrize("M,D", [(37, 128), (1000, 768), (130, 1024), (64, 192)])
 def test_layernorm(dt, M, D):
     x = rnd(M, D, seed=12, scale=3.0).to(DEV) + 0.5
