@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default="gpurun_out/kernels.json")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--variants", default="0", help="comma list of pa_gemm_args.tune values to time the NT GEMMs with")
     args = ap.parse_args()
     B, N, D, H = args.batch, 474, 768, 12
     M = B * N
@@ -80,8 +81,11 @@ def main():
             kw = dict(bias=bias, resid=xf, out_f32=torch.empty(M, Nn, device=DEV))
         elif epi == EPI_DGELU:
             kw = dict(aux=rnd(M, Nn), out_lp=torch.empty(M, Nn, device=DEV, dtype=bf))
-        sec = timeit(lambda: ops.gemm_nt(A, W, PA_BF16, epi, **kw), args.iters)
-        add(name + f" M{M} N{Nn} K{K}", sec, flops=2.0 * M * Nn * K)
+        for var in [int(v) for v in args.variants.split(",")]:
+            ops.GEMM_TUNE = var
+            sec = timeit(lambda: ops.gemm_nt(A, W, PA_BF16, epi, **kw), args.iters)
+            add(name + f" M{M} N{Nn} K{K} [variant {var}]", sec, flops=2.0 * M * Nn * K)
+        ops.GEMM_TUNE = 0
     # ---- weight-gradient GEMMs (TN, in place) ----
     for name, dY, X in (("wgrad qkv", rnd(M, 3 * D), x), ("wgrad proj", x, x), ("wgrad fc1", h, x), ("wgrad fc2", x, h)):
         dW = torch.empty(dY.shape[1], X.shape[1], device=DEV)

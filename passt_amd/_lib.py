@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ("lda", i32), ("ldb", i32), ("A", vp), ("B", vp), ("bias", vp), ("resid", vp),
                 ("ldr", i32), ("row_mod", i32), ("out_batch_rows", i32), ("out_row_off", i32),
                 ("aux", vp), ("ldaux", i32), ("out_f32", vp), ("ldo32", i32), ("out_lp", vp),
-                ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32)]
+                ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32), ("tune", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/passt_amd.h declares

@@ -18,53 +18,42 @@ namespace pa {
 
 static constexpr int BM = 128, BN = 128, KB = 128;  // KB: K bytes per step
 static constexpr int TILE_BYTES = BM * KB;            // 16 KiB per operand tile
-static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB
+static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
+#ifndef PA_GEMM_DEFAULT_VARIANT
+#define PA_GEMM_DEFAULT_VARIANT 1
+#endif
 
 
-// 8 consecutive elements <-> 8 floats; `cnt` < 8 takes the scalar tail path.
-template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8], int cnt);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], int cnt) {
-    if (cnt >= 8) {
-        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    } else {
-        for (int e = 0; e < cnt; ++e) p[e] = v[e];
-    }
+// 8 consecutive elements <-> 8 floats (16-byte vectors; N % 8 == 0 is an API precondition)
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
-template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8], int cnt) {
-    if (cnt >= 8) {
-        bf16x8 o;
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *(bf16x8*)p = o;
-    } else {
-        for (int e = 0; e < cnt; ++e) p[e] = (bf16)v[e];
-    }
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *(bf16x8*)p = o;
 }
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8], int cnt);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8], int cnt) {
-    if (cnt >= 8) {
-        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = e < cnt ? p[e] : 0.f;
-    }
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
 }
-template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8], int cnt) {
-    if (cnt >= 8) {
-        const bf16x8 a = *(const bf16x8*)p;
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+    const bf16x8 a = *(const bf16x8*)p;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = e < cnt ? (float)p[e] : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
 }
 
 // Shared epilogue: the 2x2 MFMA accumulators of this wave (64x64 outputs at rows m0 + wr*64, columns
 // n0 + wc*64) -> per-wave LDS slab -> 8-wide row vectors with the fused epilogue math.
+// vmcnt counts stores as well as loads on CDNA and retires in order, so a wait for ANY load also waits for
+// every store issued before it: the bias is therefore settled once up front (with the waitcnt builtin, which
+// the compiler's own wait insertion understands), and each 32-row pass issues all of its auxiliary loads
+// first and then all of its stores back to back, with no wait in between.
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[2][2], char* smem, int m0,
                                               int n0, int wave, int wr, int wc, int lane) {
@@ -72,16 +61,17 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
     float* slab = (float*)smem + wave * (32 * 68);
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
     const int ncol = n0 + wc * 64 + ecol;
+    const bool colok = ncol < a.N;               // N % 8 == 0: the lane's 8-vector is all in or all out
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
     if constexpr (EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU) {
         if (a.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = (ncol + e < a.N) ? a.bias[ncol + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bias8[e] = colok ? a.bias[ncol + e] : 0.f;
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): bias landed; nothing below waits on it again
     }
-    const bool full_n = ncol + 8 <= a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -89,93 +79,145 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[acc_row(r, lane) * 68 + j * 32 + (lane & 31)] = acc[i][j][r];
         // same-wave LDS RAW: the LDS queue is in order per wave; no barrier needed
+        float v[4][8], x[4][8];
+        int mrow[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + erow;
             const int m = m0 + wr * 64 + i * 32 + row;
+            mrow[it] = (m < a.M && colok) ? m : -1;
             const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
             const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
-            if (m >= a.M || ncol >= a.N) continue;
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bias8[e]; v[4 + e] = hi[e] + bias8[4 + e]; }
+            for (int e = 0; e < 4; ++e) { v[it][e] = lo[e] + bias8[e]; v[it][4 + e] = hi[e] + bias8[4 + e]; }
+        }
+        // ---- all auxiliary loads of this pass ----
+        if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_DGELU) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
+                if (mrow[it] >= 0) {
+                    if constexpr (EPI == PA_EPI_RESID) {
+                        const int64_t rrow = a.row_mod > 0 ? mrow[it] % a.row_mod : mrow[it];
+                        load8<float>(a.resid + rrow * a.ldr + ncol, x[it]);
+                    } else {
+                        load8<T>((const T*)a.aux + (int64_t)mrow[it] * a.ldaux + ncol, x[it]);
+                    }
+                }
+            }
+        }
+        // ---- math + all stores of this pass ----
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = mrow[it];
+            if (m < 0) continue;
             if constexpr (EPI == PA_EPI_STORE) {
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
             } else if constexpr (EPI == PA_EPI_GELU) {
                 float g[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[e])));
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
-                store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g, full_n ? 8 : a.N - ncol);
+                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[it][e])));
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
+                store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g);
             } else if constexpr (EPI == PA_EPI_RESID) {
-                int64_t rrow = m, orow = m;
-                if (a.row_mod > 0) {
-                    rrow = m % a.row_mod;
-                    orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + rrow;
-                }
-                float rs[8];
-                load8<float>(a.resid + rrow * a.ldr + ncol, rs, full_n ? 8 : a.N - ncol);
+                int64_t orow = m;
+                if (a.row_mod > 0) orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + m % a.row_mod;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rs[e];
-                store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v, full_n ? 8 : a.N - ncol);
+                for (int e = 0; e < 8; ++e) v[it][e] += x[it][e];
+                store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v[it]);
             } else if constexpr (EPI == PA_EPI_DGELU) {
-                float pre[8];
-                load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, pre, full_n ? 8 : a.N - ncol);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(pre[e]);
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v, full_n ? 8 : a.N - ncol);
+                for (int e = 0; e < 8; ++e) v[it][e] *= gelu_erf_grad(x[it][e]);
+                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
             } else {  // PA_EPI_PARTIAL
-                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v,
-                              full_n ? 8 : a.N - ncol);
+                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v[it]);
             }
         }
     }
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_n,
-                                                      const int nwg, const int ksteps_per_split) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `k * PER` of this wave's global->LDS copies are still in flight (k = 0..3)
+template <int PER> __device__ __forceinline__ void wait_vm_groups(int k) {
+    switch (k) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<PER>(); break;
+        case 2: wait_vmcnt<2 * PER>(); break;
+        default: wait_vmcnt<3 * PER>(); break;
+    }
+}
+
+// L2-friendly tile order: consecutive workgroup ids (which the XCD remap keeps on one XCD) walk down GROUP_M
+// row-tiles of one column-tile before moving to the next column, so the ~64 co-resident workgroups of an
+// XCD touch a GROUP_M x 8 patch of tiles (A and B panels both reused from the 4 MiB L2).
+__device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int g = pid / per_group;
+    const int first = g * group_m;
+    const int gm = min(tiles_m - first, group_m);
+    const int r = pid - g * per_group;
+    tm = first + r % gm;
+    tn = r / gm;
+}
+
+// WM = wave rows (2 -> 128-row tile, 4 -> 256-row tile); 2 wave columns; STAGES-deep LDS ring.
+template <typename T, int EPI, int WM, int STAGES>
+__global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+                                                           const int nwg, const int ksteps_per_split) {
+    constexpr int TBM = 64 * WM;                      // tile rows
+    constexpr int A_BYTES = TBM * KB, B_BYTES = BN * KB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NW = 2 * WM;                        // waves
+    constexpr int A_PER = (A_BYTES / 1024) / NW;      // A copies per wave per stage (4)
+    constexpr int B_PER = (B_BYTES / 1024) / NW;      // B copies per wave per stage (4 / 2)
+    constexpr int PER = A_PER + B_PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    const int bid = xcd_swizzle(blockIdx.x, nwg);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    int tm, tn;
+    tile_coords(xcd_swizzle(blockIdx.x, nwg), tiles_m, tiles_n, 1024 / TBM, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * BN;
     const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int ks_end = min(ksteps_total, ks_begin + ksteps_per_split);
     const int nsteps = ks_end - ks_begin;
 
-    // ---- per-lane source addresses of the 8 global->LDS copies this wave issues per stage ----
-    // wave-instruction i (0..3) of this wave fills LDS bytes [(wave*4+i)*1024, +1024) of a tile:
-    // lane -> physical 16-byte chunk q = (wave*4+i)*64 + lane -> row q>>3, physical chunk q&7,
-    // which must hold logical chunk (q&7) ^ swz_f128(row).
-    const char* srcA[4];
-    const char* srcB[4];
+    // per-lane source addresses: wave-instruction i of this wave fills LDS bytes [(wave*PERX+i)*1024, +1024)
+    // of the A (resp. B) tile: lane -> physical chunk q -> row q>>3, logical chunk (q&7) ^ swz_f128(row).
+    const char* srcA[A_PER];
+    const char* srcB[B_PER];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = (wave * 4 + i) * 64 + lane;
+    for (int i = 0; i < A_PER; ++i) {
+        const int q = (wave * A_PER + i) * 64 + lane;
         const int row = q >> 3;
         const int c = (q & 7) ^ swz_f128(row);
         const int gm = min(m0 + row, a.M - 1);
-        const int gn = min(n0 + row, a.N - 1);
         srcA[i] = (const char*)a.A + ((int64_t)gm * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int q = (wave * B_PER + i) * 64 + lane;
+        const int row = q >> 3;
+        const int c = (q & 7) ^ swz_f128(row);
+        const int gn = min(n0 + row, a.N - 1);
         srcB[i] = (const char*)a.B + ((int64_t)gn * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
     }
     auto stage = [&](int buf, int step) {
-        char* sA = smem + buf * (2 * TILE_BYTES) + wave * 4096;
-        char* sB = sA + TILE_BYTES;
+        char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
+        char* sB = smem + buf * STAGE_BYTES + A_BYTES + wave * (B_PER * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PER; ++i)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
                 (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KB),
                 (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
-        }
     };
 
     f32x16 acc[2][2];
@@ -192,13 +234,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, cons
     const int offB = (wc * 64 + (lane & 31)) * 128;
     const int half = lane >> 5;
 
-    if (nsteps > 0) stage(0, 0);
+    // prologue: fill STAGES-1 ring slots
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nsteps) stage(p, p);
+    int buf = 0;
     for (int t = 0; t < nsteps; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of tile t landed
-        __syncthreads();                         // everyone's copies landed; buffer (t+1)&1 is free
-        if (t + 1 < nsteps) stage((t + 1) & 1, t + 1);
-        const char* sA = smem + (t & 1) * (2 * TILE_BYTES);
-        const char* sB = sA + TILE_BYTES;
+        // tile t must have landed; up to min(STAGES-2, nsteps-1-t) younger tiles may stay in flight
+        wait_vm_groups<PER>(min(STAGES - 2, nsteps - 1 - t));
+        __builtin_amdgcn_s_barrier();     // raw barrier: keeps the younger copies in flight (no vmcnt(0))
+        // everyone has finished reading ring slot (t-1)%STAGES during iteration t-1: refill it with tile t+STAGES-1
+        if (t + STAGES - 1 < nsteps) {
+            int nb = buf + STAGES - 1;
+            if (nb >= STAGES) nb -= STAGES;
+            stage(nb, t + STAGES - 1);
+        }
+        const char* sA = smem + buf * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = ((ks * 2 + half) ^ rsw) << 4;
@@ -213,26 +265,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const pa_gemm_args a, cons
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
         }
+        if (++buf == STAGES) buf = 0;
     }
-
     gemm_epilogue<T, EPI>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
-template <typename T, int EPI>
-static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
-    const int tiles_m = (int)cdiv(a.M, BM), tiles_n = (int)cdiv(a.N, BN);
+template <typename T, int EPI, int WM, int STAGES>
+static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
+    constexpr int TBM = 64 * WM;
+    constexpr int LDS = STAGES * (TBM + BN) * KB;
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    static_assert(LDS >= 2 * WM * 32 * 68 * 4, "epilogue slabs must fit");
+    const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, BN);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) == hipSuccess;
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, STAGES>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(nwg, splits), dim3(256), GEMM_LDS, st, a,
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, STAGES>), dim3(nwg, splits), dim3(WM * 128), LDS, st, a, tiles_m,
                        tiles_n, nwg, per);
     return check_launch();
+}
+
+// a.tune selects the tile/pipeline variant (0 = default heuristic); see include/passt_amd.h
+template <typename T, int EPI>
+static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
+    int v = a.tune;
+    if (v == 0) v = PA_GEMM_DEFAULT_VARIANT;
+    if constexpr (sizeof(T) == 4) return launch_gemm_v<T, EPI, 2, 2>(a, st);   // parity mode: one variant
+    else {
+        switch (v) {
+            case 1: return launch_gemm_v<T, EPI, 2, 2>(a, st);     // 128x128, 2-stage, 2 workgroups / CU
+            case 2: return launch_gemm_v<T, EPI, 2, 4>(a, st);     // 128x128, 4-stage ring (128 KiB), 1 / CU
+            case 3: return launch_gemm_v<T, EPI, 4, 3>(a, st);     // 256x128, 3-stage ring (144 KiB), 8 waves
+            case 4: return launch_gemm_v<T, EPI, 2, 5>(a, st);     // 128x128, 5-stage ring (160 KiB)
+            case 5: return launch_gemm_v<T, EPI, 4, 2>(a, st);     // 256x128, 2-stage (96 KiB)
+        }
+        return PA_EINVAL;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,11 +480,10 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict_
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    const bool full = c0 + 8 <= C;
     for (int r = r_begin + ty; r < r_end; r += 32) {
         float v[8];
-        if (c0 < C) {
-            load8<T>(in + (int64_t)r * ld + c0, v, full ? 8 : C - c0);
+        if (c0 < C) {     // C % 8 == 0
+            load8<T>(in + (int64_t)r * ld + c0, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += v[e];
         }
@@ -512,6 +585,7 @@ extern "C" int pa_gemm_nt(const pa_gemm_args* a, void* stream) {
     if ((a->K * es) % KB) return PA_EUNSUPPORTED;
     if ((a->lda * es) % 16 || (a->ldb * es) % 16) return PA_EUNSUPPORTED;
     if (a->epilogue != PA_EPI_PARTIAL && a->split_k > 1) return PA_EINVAL;
+    if (a->N % 8) return PA_EUNSUPPORTED;
     // the epilogue moves 8-element vectors: every output / auxiliary leading dimension must keep
     // them 16-byte aligned
     if (a->out_lp && a->ldolp % 8) return PA_EUNSUPPORTED;
@@ -580,7 +654,7 @@ extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     if (a->epilogue != PA_EPI_PARTIAL) return PA_EUNSUPPORTED;
     const size_t es = a->dtype == PA_BF16 ? 2 : 4;
     if ((a->lda * es) % 16 || (a->ldb * es) % 16 || a->ldo32 % 4) return PA_EUNSUPPORTED;
-    if (a->M < (int)(16 / es) || a->N < (int)(16 / es)) return PA_EUNSUPPORTED;
+    if (a->M < (int)(16 / es) || a->N < (int)(16 / es) || a->N % 8 || a->M % (int)(16 / es)) return PA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == PA_BF16) return launch_gemm_tn<bf16>(*a, st);
     if (a->dtype == PA_F32) return launch_gemm_tn<float>(*a, st);
@@ -593,7 +667,7 @@ extern "C" int pa_colsum(const void* in, int dtype, int R, int C, int ld, float*
                          void* stream) {
     if (!in || !out || !ws || R <= 0 || C <= 0) return PA_EINVAL;
     const size_t es = dtype == PA_BF16 ? 2 : 4;
-    if ((ld * es) % 16) return PA_EUNSUPPORTED;
+    if ((ld * es) % 16 || C % 8) return PA_EUNSUPPORTED;
     const int rblocks = (int)std::min<int64_t>(64, cdiv(R, 256));
     const int rpb = (int)cdiv(R, rblocks);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)rblocks);

@@ -31,6 +31,7 @@ def _p(t):
 # bench.py sets this to a dict to time every GEMM launch with HIP events on the launch stream:
 # {epilogue: [(start_event, end_event, algorithmic_flops)]}
 GEMM_PROFILE = None
+GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
 
 
@@ -120,6 +121,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.out_lp2 = _p(out_lp2)
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
+    a.tune = GEMM_TUNE
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
         return

@@ -47,7 +47,7 @@ def test_ctypes_structs_match_the_c_layout():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
          offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
-         offsetof(pa_gemm_args, split_k), sizeof(pa_mel_params));
+         offsetof(pa_gemm_args, tune), sizeof(pa_mel_params));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -56,7 +56,7 @@ int main(void) {
         out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
     G = _lib.GemmArgs
     got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
-           G.split_k.offset, ctypes.sizeof(_lib.MelParams)]
+           G.tune.offset, ctypes.sizeof(_lib.MelParams)]
     assert got == [int(v) for v in out]
 
 
