@@ -30,24 +30,29 @@ template <typename T> struct Tile {
     static constexpr int NFRAG = RB / 32;                      // row fragments per row: 4 / 8
 };
 
-// global [rows][ld] (row index clamped to nrows-1) -> swizzled LDS tile, all 256 threads
+// global [rows][ld] (row index clamped to nrows-1) -> swizzled LDS tile by LDS-DMA (global_load_lds_dwordx4,
+// no VGPR round trip).  A wave-instruction fills 1 KiB lane-linearly, so the XOR swizzle is applied to the
+// per-lane SOURCE chunk (guide rule 21).  All 4 waves cooperate: BYTES/4096 instructions per wave.
 template <typename T>
-__device__ __forceinline__ void load_tile(char* lds, const T* g, int64_t ld, int row0, int nrows, int tid) {
-    constexpr int PER = TROWS * Tile<T>::CPR / 256;            // 2 / 4 chunks per thread
-    uint4 v[PER];
+__device__ __forceinline__ void stage_tile(char* lds, const T* g, int64_t ld, int row0, int nrows, int wave, int lane) {
+    constexpr int PER_WAVE = Tile<T>::BYTES / 4096;             // 2 (bf16) / 4 (f32)
+    constexpr int RPI = 1024 / Tile<T>::RB;                     // tile rows per wave-instruction: 8 / 4
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int q = it * 256 + tid;
-        const int row = q / Tile<T>::CPR, c = q % Tile<T>::CPR;
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int q = wave * PER_WAVE + i;
+        const int row = q * RPI + lane / Tile<T>::CPR;
+        const int pc = lane % Tile<T>::CPR;
+        const int c = Tile<T>::RB == 128 ? (pc ^ swz_f128(row)) : (pc ^ (row & 15));
         const int gr = min(row0 + row, nrows - 1);
-        v[it] = *(const uint4*)(g + (int64_t)gr * ld + c * Tile<T>::EPC);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(g + (int64_t)gr * ld + c * Tile<T>::EPC),
+            (__attribute__((address_space(3))) void*)(lds + q * 1024), 16, 0, 0);
     }
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int q = it * 256 + tid;
-        const int row = q / Tile<T>::CPR, c = q % Tile<T>::CPR;
-        *(uint4*)(lds + swz<Tile<T>::RB>(row, c)) = v[it];
-    }
+}
+// 64 consecutive floats (index clamped) -> LDS, one 4-byte LDS-DMA per lane, issued by ONE wave
+__device__ __forceinline__ void stage_f32x64(float* lds, const float* g, int i0, int n, int lane) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + min(i0 + lane, n - 1)),
+                                     (__attribute__((address_space(3))) void*)lds, 4, 0, 0);
 }
 
 // row fragment s of tile row `row`: 16 bytes at logical chunk s*2 + (lane>>5)
@@ -110,8 +115,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
                                                        int ldo, float* __restrict__ lse, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + Tile<T>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -134,11 +137,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const float sl2 = scale * LOG2E;
 
     const int ntiles = (N + TROWS - 1) / TROWS;
+    // double-buffered K/V tiles: stage kt+1 by LDS-DMA while computing kt; one barrier per tile
+    auto stage = [&](int buf, int kt) {
+        char* sb = smem + buf * (2 * Tile<T>::BYTES);
+        stage_tile<T>(sb, base + D, ldqkv, kt * TROWS, N, wave, lane);
+        stage_tile<T>(sb + Tile<T>::BYTES, base + 2 * D, ldqkv, kt * TROWS, N, wave, lane);
+    };
+    stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        load_tile<T>(sK, base + D, ldqkv, kt * TROWS, N, tid);
-        load_tile<T>(sV, base + 2 * D, ldqkv, kt * TROWS, N, tid);
-        __syncthreads();
+        if (kt + 1 < ntiles) stage((kt + 1) & 1, kt + 1);
+        const char* sK = smem + (kt & 1) * (2 * Tile<T>::BYTES);
+        const char* sV = sK + Tile<T>::BYTES;
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -221,10 +232,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;
-    char* sDO = smem + Tile<T>::BYTES;
-    float* sLse = (float*)(smem + 2 * Tile<T>::BYTES);
-    float* sDelta = sLse + TROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -250,16 +257,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
     const float sl2 = scale * LOG2E;
 
     const int ntiles = (N + TROWS - 1) / TROWS;
+    constexpr int STAGE = 2 * Tile<T>::BYTES + 2 * TROWS * 4;   // Q tile, dO tile, lse[64], delta[64]
+    auto stage = [&](int buf, int qt) {
+        char* sb = smem + buf * STAGE;
+        stage_tile<T>(sb, base, ldqkv, qt * TROWS, N, wave, lane);
+        stage_tile<T>(sb + Tile<T>::BYTES, dobase, ldo, qt * TROWS, N, wave, lane);
+        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), lse + (int64_t)bh * N, qt * TROWS, N, lane);
+        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, delta + (int64_t)bh * N, qt * TROWS, N, lane);
+    };
+    stage(0, 0);
     for (int qt = 0; qt < ntiles; ++qt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        load_tile<T>(sQ, base, ldqkv, qt * TROWS, N, tid);
-        load_tile<T>(sDO, dobase, ldo, qt * TROWS, N, tid);
-        if (tid < TROWS) {
-            const int q = min(qt * TROWS + tid, N - 1);
-            sLse[tid] = lse[(int64_t)bh * N + q] * LOG2E;
-            sDelta[tid] = delta[(int64_t)bh * N + q];
-        }
-        __syncthreads();
+        if (qt + 1 < ntiles) stage((qt + 1) & 1, qt + 1);
+        const char* sQ = smem + (qt & 1) * STAGE;
+        const char* sDO = sQ + Tile<T>::BYTES;
+        const float* sLse = (const float*)(sQ + 2 * Tile<T>::BYTES);
+        const float* sDelta = sLse + TROWS;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sa, dpa;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
             for (int r = 0; r < 16; ++r) {
                 const int ql = qb * 32 + acc_row(r, lane);
                 const bool valid = (qt * TROWS + ql < N) && (key < N);
-                const float p = valid ? exp2f(sa[r] * sl2 - sLse[ql]) : 0.f;
+                const float p = valid ? exp2f(sa[r] * sl2 - sLse[ql] * LOG2E) : 0.f;
                 sa[r] = p;                                   // P
                 dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;  // dS
             }
@@ -309,8 +323,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + Tile<T>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -338,11 +350,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     const float sl2 = scale * LOG2E;
 
     const int ntiles = (N + TROWS - 1) / TROWS;
+    auto stage = [&](int buf, int kt) {
+        char* sb = smem + buf * (2 * Tile<T>::BYTES);
+        stage_tile<T>(sb, base + D, ldqkv, kt * TROWS, N, wave, lane);
+        stage_tile<T>(sb + Tile<T>::BYTES, base + 2 * D, ldqkv, kt * TROWS, N, wave, lane);
+    };
+    stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        load_tile<T>(sK, base + D, ldqkv, kt * TROWS, N, tid);
-        load_tile<T>(sV, base + 2 * D, ldqkv, kt * TROWS, N, tid);
-        __syncthreads();
+        if (kt + 1 < ntiles) stage((kt + 1) & 1, kt + 1);
+        const char* sK = smem + (kt & 1) * (2 * Tile<T>::BYTES);
+        const char* sV = sK + Tile<T>::BYTES;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 sa, dpa;
@@ -376,8 +395,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                         lddqkv, q0, min(32, N - q0), lane);
 }
 
-template <typename T> static size_t fwd_lds() { return std::max<size_t>(2 * Tile<T>::BYTES, SLAB_BYTES); }
-template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * Tile<T>::BYTES + 2 * TROWS * 4, SLAB_BYTES); }
+template <typename T> static size_t fwd_lds() { return std::max<size_t>(4 * Tile<T>::BYTES, SLAB_BYTES); }
+template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * (2 * Tile<T>::BYTES + 2 * TROWS * 4), SLAB_BYTES); }
 
 template <typename T>
 static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,

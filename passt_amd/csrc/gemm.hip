@@ -251,19 +251,25 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const pa_gemm_args a,
         }
         const char* sA = smem + buf * STAGE_BYTES;
         const char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        // fragment double buffer: the ds_read_b128s of k-substep ks+1 are issued before the MFMAs of ks, so
+        // LDS latency overlaps the matrix pipe inside one wave (not only across the waves of a SIMD)
+        typename Frag<T>::type fa[2][2], fb[2][2];
+        auto read_frags = [&](int slot, int ks) {
             const int coff = ((ks * 2 + half) ^ rsw) << 4;
-            typename Frag<T>::type fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
-                fb[i] = *(const typename Frag<T>::type*)(sB + offB + i * 32 * 128 + coff);
+                fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+                fb[slot][i] = *(const typename Frag<T>::type*)(sB + offB + i * 32 * 128 + coff);
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) read_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
         }
         if (++buf == STAGES) buf = 0;
     }
