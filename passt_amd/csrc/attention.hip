@@ -159,36 +159,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
             for (int st = 0; st < Tile<T>::NFRAG; ++st)
                 mma32<T>(s[kb], row_frag<T>(sK, kb * 32 + (lane & 31), st, lane), qf[st]);
         }
-        // online softmax; this lane owns query (lane&31) and 16 of the 32 keys of each key block
-        float mloc = -INFINITY;
+        // online softmax; this lane owns query (lane&31) and 16 of the 32 keys of each key block.
+        // Keys beyond N exist only in the last tile: the mask is a wave-uniform branch.
+        if (kt == ntiles - 1 && (N & (TROWS - 1))) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * TROWS + kb * 32 + acc_row(r, lane) >= N) s[kb][r] = -INFINITY;
+        }
+        float mloc = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * TROWS + kb * 32 + acc_row(r, lane);
-                const float v = key < N ? s[kb][r] * sl2 : -INFINITY;
-                s[kb][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mloc * sl2);         // running max in log2 units (sl2 > 0)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_new));
                 s[kb][r] = p;
                 psum += p;
             }
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                          // no row max moved: skip the O rescale
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
         // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
     __syncthreads();   // tiles are dead; reuse LDS for the transposed store
     if (q0 < N) {
-        if (lane < 32 && q0 + lane < N) lse[(int64_t)bh * N + q0 + lane] = m_run * LN2 + __logf(l_run);
+        if (lane < 32 && q0 + lane < N) lse[(int64_t)bh * N + q0 + lane] = m_run * LN2 + __logf(l_run);   // natural log units
         store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, 1.0f / l_run, o + (int64_t)b * N * ldo + h * HD,
                         ldo, q0, min(32, N - q0), lane);
     }
@@ -288,10 +293,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qb * 32 + acc_row(r, lane);
-                const bool valid = (qt * TROWS + ql < N) && (key < N);
-                const float p = valid ? exp2f(sa[r] * sl2 - sLse[ql] * LOG2E) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -sLse[ql] * LOG2E));
                 sa[r] = p;                                   // P
                 dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;  // dS
+            }
+            // queries beyond N exist only in the last tile (uniform branch); lanes whose own key is beyond
+            // N only produce their own, never stored, outputs and need no mask
+            if (qt == ntiles - 1 && (N & (TROWS - 1))) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (qt * TROWS + qb * 32 + acc_row(r, lane) >= N) { sa[r] = 0.f; dpa[r] = 0.f; }
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
@@ -375,9 +386,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * TROWS + kb * 32 + acc_row(r, lane);
-                const float p = key < N ? exp2f(sa[r] * sl2 - lse2) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -lse2));
                 dpa[r] = p * (dpa[r] - dlt) * scale;   // dS^T
+            }
+            if (kt == ntiles - 1 && (N & (TROWS - 1))) {       // keys beyond N: last tile only
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * TROWS + kb * 32 + acc_row(r, lane) >= N) dpa[r] = 0.f;
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
