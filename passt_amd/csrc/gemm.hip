@@ -54,8 +54,8 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v
 // every store issued before it: the bias is therefore settled once up front (with the waitcnt builtin, which
 // the compiler's own wait insertion understands), and each 32-row pass issues all of its auxiliary loads
 // first and then all of its stores back to back, with no wait in between.
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[2][2], char* smem, int m0,
+template <typename T, int EPI, int TM = 2>
+__device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* smem, int m0,
                                               int n0, int wave, int wr, int wc, int lane) {
     __syncthreads();  // every wave is done reading the operand tiles; LDS is reused below
     float* slab = (float*)smem + wave * (32 * 68);
@@ -73,7 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): bias landed; nothing below waits on it again
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -84,7 +84,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + erow;
-            const int m = m0 + wr * 64 + i * 32 + row;
+            const int m = m0 + wr * (TM * 32) + i * 32 + row;
             mrow[it] = (m < a.M && colok) ? m : -1;
             const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
             const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
@@ -161,25 +161,28 @@ __device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, i
     tn = r / gm;
 }
 
-// WM = wave rows (2 -> 128-row tile, 4 -> 256-row tile); 2 wave columns; STAGES-deep LDS ring.
-template <typename T, int EPI, int WM, int STAGES>
-__global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
-                                                           const int nwg, const int ksteps_per_split) {
-    constexpr int TBM = 64 * WM;                      // tile rows
-    constexpr int A_BYTES = TBM * KB, B_BYTES = BN * KB, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NW = 2 * WM;                        // waves
-    constexpr int A_PER = (A_BYTES / 1024) / NW;      // A copies per wave per stage (4)
-    constexpr int B_PER = (B_BYTES / 1024) / NW;      // B copies per wave per stage (4 / 2)
+// Workgroup tile = (WM*TM*32) x (WN*64): WM x WN waves, each owning TM x 2 MFMA 32x32 accumulators
+// (wave tile TM*32 rows x 64 columns); STAGES-deep LDS ring.  Larger wave tiles cut LDS bytes per MFMA
+// (fragments per MFMA: (TM+2)/(2 TM) = 1.0 at TM=2, 0.75 at TM=4).
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+                                                               const int nwg, const int ksteps_per_split) {
+    constexpr int TBM = WM * TM * 32, TBN = WN * 64;
+    constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NW = WM * WN;
+    constexpr int A_PER = (A_BYTES / 1024) / NW;      // A copies per wave per stage
+    constexpr int B_PER = (B_BYTES / 1024) / NW;      // B copies per wave per stage
     constexpr int PER = A_PER + B_PER;
+    static_assert(A_PER * NW * 1024 == A_BYTES && B_PER * NW * 1024 == B_BYTES, "tile must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
     int tm, tn;
     tile_coords(xcd_swizzle(blockIdx.x, nwg), tiles_m, tiles_n, 1024 / TBM, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * TBN;
     const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int ks_end = min(ksteps_total, ks_begin + ksteps_per_split);
@@ -220,17 +223,17 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const pa_gemm_args a,
                 (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // read offsets: row = w*64 + i*32 + (lane&31); swz_f128(row) == swz_f128(lane) for every i
+    // read offsets: row = base + i*32 + (lane&31); swz_f128(row) == swz_f128(lane) for every i
     const int rsw = swz_f128(lane);
-    const int offA = (wr * 64 + (lane & 31)) * 128;
+    const int offA = (wr * (TM * 32) + (lane & 31)) * 128;
     const int offB = (wc * 64 + (lane & 31)) * 128;
     const int half = lane >> 5;
 
@@ -253,47 +256,46 @@ __global__ __launch_bounds__(WM * 128) void gemm_nt_kernel(const pa_gemm_args a,
         const char* sB = sA + A_BYTES;
         // fragment double buffer: the ds_read_b128s of k-substep ks+1 are issued before the MFMAs of ks, so
         // LDS latency overlaps the matrix pipe inside one wave (not only across the waves of a SIMD)
-        typename Frag<T>::type fa[2][2], fb[2][2];
+        typename Frag<T>::type fa[2][TM], fb[2][2];
         auto read_frags = [&](int slot, int ks) {
             const int coff = ((ks * 2 + half) ^ rsw) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
-                fb[slot][i] = *(const typename Frag<T>::type*)(sB + offB + i * 32 * 128 + coff);
-            }
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[slot][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
         };
         read_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
         }
         if (++buf == STAGES) buf = 0;
     }
-    gemm_epilogue<T, EPI>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+    gemm_epilogue<T, EPI, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
-template <typename T, int EPI, int WM, int STAGES>
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
 static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
-    constexpr int TBM = 64 * WM;
-    constexpr int LDS = STAGES * (TBM + BN) * KB;
+    constexpr int TBM = WM * TM * 32, TBN = WN * 64;
+    constexpr int LDS = STAGES * (TBM + TBN) * KB;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
-    static_assert(LDS >= 2 * WM * 32 * 68 * 4, "epilogue slabs must fit");
-    const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, BN);
+    static_assert(LDS >= WM * WN * 32 * 68 * 4, "epilogue slabs must fit");
+    const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, TBN);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, STAGES>,
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, STAGES>), dim3(nwg, splits), dim3(WM * 128), LDS, st, a, tiles_m,
-                       tiles_n, nwg, per);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
+                       tiles_m, tiles_n, nwg, per);
     return check_launch();
 }
 
@@ -302,14 +304,14 @@ template <typename T, int EPI>
 static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
     int v = a.tune;
     if (v == 0) v = PA_GEMM_DEFAULT_VARIANT;
-    if constexpr (sizeof(T) == 4) return launch_gemm_v<T, EPI, 2, 2>(a, st);   // parity mode: one variant
+    if constexpr (sizeof(T) == 4) return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // parity mode: one variant
     else {
         switch (v) {
-            case 1: return launch_gemm_v<T, EPI, 2, 2>(a, st);     // 128x128, 2-stage, 2 workgroups / CU
-            case 2: return launch_gemm_v<T, EPI, 2, 4>(a, st);     // 128x128, 4-stage ring (128 KiB), 1 / CU
-            case 3: return launch_gemm_v<T, EPI, 4, 3>(a, st);     // 256x128, 3-stage ring (144 KiB), 8 waves
-            case 4: return launch_gemm_v<T, EPI, 2, 5>(a, st);     // 128x128, 5-stage ring (160 KiB)
-            case 5: return launch_gemm_v<T, EPI, 4, 2>(a, st);     // 256x128, 2-stage (96 KiB)
+            case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
+            case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), 2-stage, 128 KiB
+            case 3: return launch_gemm_v<T, EPI, 4, 2, 2, 3>(a, st);   // 256x128, 8 waves (64x64 each), 3-stage ring
+            case 4: return launch_gemm_v<T, EPI, 1, 4, 4, 2>(a, st);   // 128x256, 4 waves (128x64 each), 2-stage, 96 KiB
+            case 5: return launch_gemm_v<T, EPI, 2, 2, 4, 2>(a, st);   // 256x128, 4 waves (128x64 each), 2-stage, 96 KiB
         }
         return PA_EINVAL;
     }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const pa_gemm_args a, cons
                 for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
         }
     }
-    gemm_epilogue<T, PA_EPI_PARTIAL>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+    gemm_epilogue<T, PA_EPI_PARTIAL, 2>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
 template <typename T>

@@ -60,6 +60,29 @@ def test_gemm_store_bias(dt, M, N, K):
     assert e < tol(dt), e
 
 
+@pytest.mark.parametrize("tune", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (300, 264, 128), (2 * 474, 2304, 256)])
+def test_gemm_tile_variants(tune, M, N, K):
+    """every workgroup-tile / pipeline variant of pa_gemm_nt (pa_gemm_args.tune) computes the same GEMM"""
+    dt = PA_BF16
+    A = rnd(M, K, seed=50).to(TD[dt]).to(DEV)
+    Bm = rnd(N, K, seed=51).to(TD[dt]).to(DEV)
+    bias = rnd(N, seed=52).to(DEV)
+    resid = rnd(M, N, seed=53).to(DEV)
+    ref = A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu()
+    old = ops.GEMM_TUNE
+    try:
+        ops.GEMM_TUNE = tune
+        out = torch.empty(M, N, device=DEV, dtype=TD[dt])
+        ops.gemm_nt(A, Bm, dt, EPI_STORE, bias=bias, out_lp=out)
+        assert rel_err(out, ref) < tol(dt)
+        out32 = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(A, Bm, dt, EPI_RESID, bias=bias, resid=resid, out_f32=out32)
+        assert rel_err(out32, ref + resid.double().cpu()) < 3e-3
+    finally:
+        ops.GEMM_TUNE = old
+
+
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
 def test_gemm_epilogues(dt):
     M, N, K = 300, 264, 128
