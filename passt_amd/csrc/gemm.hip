@@ -299,6 +299,133 @@ static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
     return check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Role-split ("staggered") 256x256 kernel.  8 waves = 2 groups x 4; group g owns rows g*128..+127, each
+// wave a 128x64 output tile (4x2 MFMA 32x32 accumulators).  A workgroup's waves w and w+4 share a SIMD, so
+// every SIMD hosts one wave of each group.  The K loop is cut into segments separated by s_barrier:
+//     L (load):  6 ds_read_b128 (fragments of ONE k-substep) + a share of the next K-tile's LDS-DMA
+//     M (math):  8 MFMA 32x32x16 under s_setprio 1
+// and group 1 runs ONE barrier behind group 0, so in every barrier interval one wave of each SIMD is in M
+// while its partner is in L: the matrix pipe and the LDS/VMEM paths are used concurrently instead of
+// alternately (guide 5.5 T3-T5, MI355X_MICROARCH "Two waves per SIMD").
+// LDS: two K-tile buffers of 64 KiB.  The DMA of tile t+1 is issued in the first two L segments of tile t
+// (>= 5 barrier intervals before its first use); every wave drains its own DMA (vmcnt 0) just before the
+// barrier that ends tile t's last interval, so the buffer is complete when either group starts reading it.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+                                                              const int nwg, const int ksteps_per_split) {
+    constexpr int TM = 4, WN = 4;
+    constexpr int TBM = 256, TBN = 256;
+    constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 64 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;      // wr = group
+    int tm, tn;
+    tile_coords(xcd_swizzle(blockIdx.x, nwg), tiles_m, tiles_n, 4, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int ks_begin = blockIdx.y * ksteps_per_split;
+    const int nsteps = min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;
+
+    const char* srcA[4];
+    const char* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (wave * 4 + i) * 64 + lane;
+        const int row = q >> 3;
+        const int c = (q & 7) ^ swz_f128(row);
+        srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        srcB[i] = (const char*)a.B + ((int64_t)min(n0 + row, a.N - 1) * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+    }
+    auto dmaA = [&](int buf, int step) {
+        char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
+                                             (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+    };
+    auto dmaB = [&](int buf, int step) {
+        char* sB = smem + buf * STAGE_BYTES + A_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KB),
+                                             (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int rsw = swz_f128(lane);
+    const int offA = (wr * 128 + (lane & 31)) * 128;
+    const int offB = (wc * 64 + (lane & 31)) * 128;
+    const int half = lane >> 5;
+
+    if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // tile 0 complete for everyone
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+
+    for (int t = 0; t < nsteps; ++t) {
+        const char* sA = smem + (t & 1) * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+        const bool more = t + 1 < nsteps;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            // ---------------- L segment ----------------
+            typename Frag<T>::type fa[TM], fb[2];
+            const int coff = ((ph * 2 + half) ^ rsw) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
+            if (more) {
+                if (ph == 0) dmaA((t + 1) & 1, t + 1);
+                if (ph == 1) dmaB((t + 1) & 1, t + 1);
+            }
+            if (ph == 3 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- M segment ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (ph == 3 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();             // re-align the two groups
+    gemm_epilogue<T, EPI, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+}
+
+template <typename T, int EPI>
+static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
+    constexpr int LDS = 2 * (256 + 256) * KB;   // 128 KiB
+    const int tiles_m = (int)cdiv(a.M, 256), tiles_n = (int)cdiv(a.N, 256);
+    const int nwg = tiles_m * tiles_n;
+    const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
+    const int per = (int)cdiv(ksteps, splits);
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI>), dim3(nwg, splits), dim3(512), LDS, st, a, tiles_m, tiles_n, nwg, per);
+    return check_launch();
+}
+
 // a.tune selects the tile/pipeline variant (0 = default heuristic); see include/passt_amd.h
 template <typename T, int EPI>
 static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
@@ -312,6 +439,7 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
             case 3: return launch_gemm_v<T, EPI, 4, 2, 2, 3>(a, st);   // 256x128, 8 waves (64x64 each), 3-stage ring
             case 4: return launch_gemm_v<T, EPI, 1, 4, 4, 2>(a, st);   // 128x256, 4 waves (128x64 each), 2-stage, 96 KiB
             case 5: return launch_gemm_v<T, EPI, 2, 2, 4, 2>(a, st);   // 256x128, 4 waves (128x64 each), 2-stage, 96 KiB
+            case 6: return launch_gemm_stagger<T, EPI>(a, st);         // 256x256 role-split schedule (8 waves)
         }
         return PA_EINVAL;
     }
