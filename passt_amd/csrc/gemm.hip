@@ -312,11 +312,12 @@ static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
 // (>= 5 barrier intervals before its first use); every wave drains its own DMA (vmcnt 0) just before the
 // barrier that ends tile t's last interval, so the buffer is complete when either group starts reading it.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
+template <typename T, int EPI, int TM>
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                               const int nwg, const int ksteps_per_split) {
-    constexpr int TM = 4, WN = 4;
-    constexpr int TBM = 256, TBN = 256;
+    constexpr int WN = 4;
+    constexpr int TBM = 64 * TM, TBN = 256;          // TM = 2/3/4 -> 128/192/256-row tiles (tile quantisation)
+    constexpr int A_PER = TM;                         // A copies per wave per stage: TBM*128/1024/8
     constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 64 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -330,20 +331,26 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int nsteps = min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;
 
-    const char* srcA[4];
+    const char* srcA[A_PER];
     const char* srcB[4];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int q = (wave * A_PER + i) * 64 + lane;
+        const int row = q >> 3;
+        const int c = (q & 7) ^ swz_f128(row);
+        srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = (wave * 4 + i) * 64 + lane;
         const int row = q >> 3;
         const int c = (q & 7) ^ swz_f128(row);
-        srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
         srcB[i] = (const char*)a.B + ((int64_t)min(n0 + row, a.N - 1) * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
     }
     auto dmaA = [&](int buf, int step) {
-        char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+        char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < A_PER; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
                                              (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
     };
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int rsw = swz_f128(lane);
-    const int offA = (wr * 128 + (lane & 31)) * 128;
+    const int offA = (wr * (TM * 32) + (lane & 31)) * 128;
     const int offB = (wc * 64 + (lane & 31)) * 128;
     const int half = lane >> 5;
 
@@ -409,20 +416,21 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     gemm_epilogue<T, EPI, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int TM>
 static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
-    constexpr int LDS = 2 * (256 + 256) * KB;   // 128 KiB
-    const int tiles_m = (int)cdiv(a.M, 256), tiles_n = (int)cdiv(a.N, 256);
+    constexpr int LDS = 2 * (64 * TM + 256) * KB;   // 96 / 112 / 128 KiB
+    static_assert(LDS >= 8 * 32 * 68 * 4, "epilogue slabs must fit");
+    const int tiles_m = (int)cdiv(a.M, 64 * TM), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI>,
+        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI>), dim3(nwg, splits), dim3(512), LDS, st, a, tiles_m, tiles_n, nwg, per);
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(nwg, splits), dim3(512), LDS, st, a, tiles_m, tiles_n, nwg, per);
     return check_launch();
 }
 
@@ -439,7 +447,9 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
             case 3: return launch_gemm_v<T, EPI, 4, 2, 2, 3>(a, st);   // 256x128, 8 waves (64x64 each), 3-stage ring
             case 4: return launch_gemm_v<T, EPI, 1, 4, 4, 2>(a, st);   // 128x256, 4 waves (128x64 each), 2-stage, 96 KiB
             case 5: return launch_gemm_v<T, EPI, 2, 2, 4, 2>(a, st);   // 256x128, 4 waves (128x64 each), 2-stage, 96 KiB
-            case 6: return launch_gemm_stagger<T, EPI>(a, st);         // 256x256 role-split schedule (8 waves)
+            case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
+            case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
+            case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split
         }
         return PA_EINVAL;
     }
