@@ -93,8 +93,12 @@ def main():
 
         def run():
             ws[0] = ops.wgrad_tn(dY, X, dW, PA_BF16, False, ws[0])
-        sec = timeit(run, args.iters)
-        add(name + f" (tn, split-K+reduce) N{dY.shape[1]} K{X.shape[1]} M{M}", sec, flops=2.0 * M * dY.shape[1] * X.shape[1])
+        for var, label in ((1, "128x128"), (0, "256x256 role-split")):
+            ops.GEMM_TUNE = var
+            sec = timeit(run, args.iters)
+            add(name + f" (tn {label}, split-K+reduce) N{dY.shape[1]} K{X.shape[1]} M{M}", sec,
+                flops=2.0 * M * dY.shape[1] * X.shape[1])
+        ops.GEMM_TUNE = 0
     db = torch.empty(4 * D, device=DEV)
     sec = timeit(lambda: ops.colsum(h, db), args.iters)
     add("colsum (bias grad) [M,3072] bf16", sec, bytes_=M * 4 * D * 2)

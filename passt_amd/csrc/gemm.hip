@@ -600,6 +600,165 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const pa_gemm_args a, cons
     gemm_epilogue<T, PA_EPI_PARTIAL, 2>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Role-split TN kernel (bf16): 256 x 256 output tile of dW, 8 waves = 2 groups x 4, wave tile 128 x 64, the
+// token axis streams through two 64 KiB LDS stages ([64 tokens][256 columns] of dY and of X).  Same
+// L / M segment structure and one-barrier stagger as gemm_nt_stagger_kernel; fragments are transpose reads.
+// The long reduction (tokens / split_k) amortises prologue and epilogue, so this kernel runs at the
+// steady-state rate of the schedule.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn2_swz(int row, int c) { return row * 512 + ((c ^ ((row & 3) << 2)) << 4); }
+
+__device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int ms, int cbase, int lane) {
+    const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int r1 = ms * 16 + h * 8 + (p >> 2);
+    const int col = cbase + g * 16 + (p & 3) * 4;
+    const int within = (col & 7) * 2;
+    const bf16x4 lo = lds_tr16(tile + tn2_swz(r1, col >> 3) + within);
+    const bf16x4 hi = lds_tr16(tile + tn2_swz(r1 + 4, col >> 3) + within);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
+                                                              const int steps_per_split) {
+    constexpr int TM = 4, WN = 4, MROWS = 64;
+    constexpr int OP_BYTES = MROWS * 512, STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int bid = xcd_swizzle(blockIdx.x, nwg);
+    const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;     // dY columns / X columns of this tile
+    const int Mtok = a.K;
+    const int steps_total = (Mtok + MROWS - 1) / MROWS;
+    const int st_begin = blockIdx.y * steps_per_split;
+    const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
+
+    // this wave's 4 + 4 LDS-DMA pieces per stage: piece q = wave*4+i covers tile rows 2q, 2q+1 (512 B each)
+    const char* srcA[4];
+    const char* srcB[4];
+    int rowin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;
+        const int row = q * 2 + (lane >> 5);
+        const int pc = lane & 31;
+        const int c = pc ^ ((row & 3) << 2);
+        rowin[i] = row;
+        srcA[i] = (const char*)a.A + (int64_t)min(m0 + c * 8, a.M - 8) * 2;
+        srcB[i] = (const char*)a.B + (int64_t)min(n0 + c * 8, a.N - 8) * 2;
+    }
+    auto dmaA = [&](int buf, int step) {
+        char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t tok = min((int64_t)(st_begin + step) * MROWS + rowin[i], (int64_t)Mtok - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + tok * a.lda * 2),
+                                             (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+        }
+    };
+    auto dmaB = [&](int buf, int step) {
+        char* sB = smem + buf * STAGE_BYTES + OP_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t tok = min((int64_t)(st_begin + step) * MROWS + rowin[i], (int64_t)Mtok - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + tok * a.ldb * 2),
+                                             (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+        }
+    };
+    // token rows beyond Mtok (last stage only) were filled from a clamped row: zero what THIS wave staged,
+    // after its DMA landed and before the barrier that publishes the stage
+    auto zero_tail = [&](int buf, int step) {
+        const int valid = Mtok - (st_begin + step) * MROWS;
+        if (valid >= MROWS) return;
+        char* sA = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (rowin[i] >= valid) {
+                const int off = (wave * 4 + i) * 1024 + lane * 16;
+                *(uint4*)(sA + off) = make_uint4(0, 0, 0, 0);
+                *(uint4*)(sA + OP_BYTES + off) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsteps > 0) zero_tail(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+
+    for (int t = 0; t < nsteps; ++t) {
+        const char* sA = smem + (t & 1) * STAGE_BYTES;
+        const char* sB = sA + OP_BYTES;
+        const bool more = t + 1 < nsteps;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            // ---------------- L segment: fragments of 16 tokens ----------------
+            bf16x8 fa[TM], fb[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = tn2_frag(sA, ph, wr * 128 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tn2_frag(sB, ph, wc * 64 + j * 32, lane);
+            if (more) {
+                if (ph == 0) dmaA((t + 1) & 1, t + 1);
+                if (ph == 1) dmaB((t + 1) & 1, t + 1);
+            }
+            if (ph == 3 && wr == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more) zero_tail((t + 1) & 1, t + 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- M segment ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (ph == 3 && wr == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more) zero_tail((t + 1) & 1, t + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    gemm_epilogue<bf16, PA_EPI_PARTIAL, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+}
+
+static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
+    constexpr int LDS = 2 * 2 * 64 * 512;   // 128 KiB
+    const int tiles_m = (int)cdiv(a.M, 256), tiles_n = (int)cdiv(a.N, 256);
+    const int nwg = tiles_m * tiles_n;
+    const int steps = (int)cdiv(a.K, 64);
+    const int per = (int)cdiv(steps, a.split_k);
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)gemm_tn_stagger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL(gemm_tn_stagger_kernel, dim3(nwg, a.split_k), dim3(512), LDS, st, a, tiles_n, nwg, per);
+    return check_launch();
+}
+
 template <typename T>
 static int launch_gemm_tn(const pa_gemm_args& a, hipStream_t st) {
     const int tiles_m = (int)cdiv(a.M, BM), tiles_n = (int)cdiv(a.N, BN);
@@ -802,7 +961,7 @@ extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     if ((a->lda * es) % 16 || (a->ldb * es) % 16 || a->ldo32 % 4) return PA_EUNSUPPORTED;
     if (a->M < (int)(16 / es) || a->N < (int)(16 / es) || a->N % 8 || a->M % (int)(16 / es)) return PA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == PA_BF16) return launch_gemm_tn<bf16>(*a, st);
+    if (a->dtype == PA_BF16) return a->tune == 1 ? launch_gemm_tn<bf16>(*a, st) : launch_gemm_tn_stagger(*a, st);
     if (a->dtype == PA_F32) return launch_gemm_tn<float>(*a, st);
     return PA_EINVAL;
 }

@@ -179,14 +179,30 @@ def wgrad(dY_t, X_t, out_f32, dtype, accumulate=False, partial_ws=None):
     return partial_ws
 
 
+def pick_split_k_slots(tiles, steps, slots=256):
+    """split count for the one-workgroup-per-CU kernels: fill whole rounds of `slots` workgroups
+    (tile quantisation), at least 8 reduction steps per slice, prefer fewer slices on ties."""
+    best, best_score = 1, -1.0
+    for S in range(1, max(1, min(64, steps // 8)) + 1):
+        blocks = tiles * S
+        eff = blocks / (((blocks + slots - 1) // slots) * slots)
+        score = eff - 0.003 * S
+        if score > best_score:
+            best, best_score = S, score
+    return best
+
+
 def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     """out[N][K] (+)= dY[M][N]^T X[M][K], operands read in place (pa_gemm_tn), deterministic split-K."""
     Mtok, N = dY.shape
     K = X.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    mrows = 64 if dtype == PA_BF16 else 32
-    steps = (Mtok + mrows - 1) // mrows
-    S = pick_split_k(tiles, steps)
+    if dtype == PA_BF16 and GEMM_TUNE != 1:      # role-split 256x256 kernel, one workgroup per CU
+        tiles = ((N + 255) // 256) * ((K + 255) // 256)
+        S = pick_split_k_slots(tiles, (Mtok + 63) // 64)
+    else:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        mrows = 64 if dtype == PA_BF16 else 32
+        S = pick_split_k(tiles, (Mtok + mrows - 1) // mrows)
     need = S * N * K
     if partial_ws is None or partial_ws.numel() < need:
         partial_ws = torch.empty(need, device=dY.device, dtype=torch.float32)
@@ -198,6 +214,7 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     a.A, a.B = _p(dY), _p(X)
     a.out_f32, a.ldo32 = _p(part), K
     a.split_k = S
+    a.tune = GEMM_TUNE
     lib = _lib.load()
     if GEMM_PROFILE is None:
         check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")

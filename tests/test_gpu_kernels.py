@@ -161,6 +161,14 @@ def test_wgrad_tn_in_place_and_colsum(dt, M, N, K):
     e = rel_err(dW, ref)
     record(f"wgrad_tn[{dt},{M},{N},{K}]", rel=e)
     assert e < tol(dt, 3e-5, 1e-4), e
+    if dt == PA_BF16:        # the 128x128 kernel (tune=1) must agree with the default role-split 256x256 one
+        old, ops.GEMM_TUNE = ops.GEMM_TUNE, 1
+        try:
+            dW1 = torch.empty((N, K), device=DEV)
+            ops.wgrad_tn(dY, X, dW1, dt, accumulate=False)
+        finally:
+            ops.GEMM_TUNE = old
+        assert rel_err(dW1, ref) < 1e-4
     ops.wgrad_tn(dY, X, dW, dt, accumulate=True)
     assert rel_err(dW, 2 * ref) < 1e-4
     db = torch.full((N,), 9.0, device=DEV)
