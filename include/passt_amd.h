@@ -137,10 +137,10 @@ typedef struct {
     void* out_lp2;
     int32_t ldolp2;
     int32_t split_k;       /* PA_EPI_PARTIAL: number of K slices (grid.z); else must be 1 */
-    int32_t tune;          /* 0 = library default; 1..5 force a tile/pipeline variant of pa_gemm_nt (bf16):
-                            * 1: 128x128 (4 waves of 64x64), 2: 256x256 (8 waves of 128x64), 3: 256x128 (8 waves of
-                            * 64x64, 3-stage ring), 4: 128x256 (4 waves of 128x64), 5: 256x128 (4 waves of 128x64)
-                            * -- benchmarking / autotuning */
+    int32_t tune;          /* 0 = library heuristic (tile quantisation x measured rates).  Forcing a variant
+                            * (benchmarking / autotuning), pa_gemm_nt bf16: 1 = 128x128 tile, 4 waves, 2 workgroups/CU;
+                            * 2 = 256x256 lockstep; 6 / 7 / 8 = role-split 256x256 / 192x256 / 128x256 (8 waves,
+                            * staggered wave groups).  pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256. */
 } pa_gemm_args;
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
 /* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major

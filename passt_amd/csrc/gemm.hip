@@ -19,9 +19,7 @@ namespace pa {
 static constexpr int BM = 128, BN = 128, KB = 128;  // KB: K bytes per step
 static constexpr int TILE_BYTES = BM * KB;            // 16 KiB per operand tile
 static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
-#ifndef PA_GEMM_DEFAULT_VARIANT
-#define PA_GEMM_DEFAULT_VARIANT 1
-#endif
+
 
 
 // 8 consecutive elements <-> 8 floats (16-byte vectors; N % 8 == 0 is an API precondition)
@@ -434,19 +432,40 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     return check_launch();
 }
 
-// a.tune selects the tile/pipeline variant (0 = default heuristic); see include/passt_amd.h
+// Variant choice when pa_gemm_args.tune == 0: minimise  rounds x tile_time  with
+//   rounds    = ceil(#tiles / resident workgroups)     (tile quantisation on 256 CUs)
+//   tile_time = tile area / steady-state rate of the schedule (relative rates measured on MI355X at the
+//               passt_s shapes, profiles/r01_*: the role-split kernels reach ~1.25-1.4 PF/s on long K but pay
+//               an un-overlapped prologue+epilogue per tile, which at K = 768 cancels their advantage)
+static int pick_nt_variant(int M, int N, int K) {
+    struct Cand { int id, bm, bn, slots; float rate_short, rate_long; };
+    static const Cand cands[] = {
+        {1, 128, 128, 512, 750.f, 930.f},
+        {8, 128, 256, 256, 650.f, 1000.f},
+        {7, 192, 256, 256, 780.f, 1250.f},
+        {6, 256, 256, 256, 760.f, 1150.f},
+    };
+    int best = 1;
+    double best_cost = 1e30;
+    for (const Cand& c : cands) {
+        const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
+        const double rounds = (double)cdiv(tiles, c.slots);
+        const double rate = (K <= 1024 ? c.rate_short : c.rate_long) / c.slots;   // per resident workgroup
+        const double cost = rounds * (double)c.bm * c.bn / rate;
+        if (cost < best_cost) { best_cost = cost; best = c.id; }
+    }
+    return best;
+}
+
+// a.tune selects the tile/pipeline variant (0 = heuristic above); see include/passt_amd.h
 template <typename T, int EPI>
 static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
-    int v = a.tune;
-    if (v == 0) v = PA_GEMM_DEFAULT_VARIANT;
     if constexpr (sizeof(T) == 4) return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // parity mode: one variant
     else {
+        const int v = a.tune ? a.tune : pick_nt_variant(a.M, a.N, a.K);
         switch (v) {
             case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
-            case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), 2-stage, 128 KiB
-            case 3: return launch_gemm_v<T, EPI, 4, 2, 2, 3>(a, st);   // 256x128, 8 waves (64x64 each), 3-stage ring
-            case 4: return launch_gemm_v<T, EPI, 1, 4, 4, 2>(a, st);   // 128x256, 4 waves (128x64 each), 2-stage, 96 KiB
-            case 5: return launch_gemm_v<T, EPI, 2, 2, 4, 2>(a, st);   // 256x128, 4 waves (128x64 each), 2-stage, 96 KiB
+            case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
             case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
             case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
             case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split
