@@ -100,9 +100,15 @@ __device__ __forceinline__ void store_rows_T(float* slab, const f32x16 (&acc)[2]
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[(lane & 31) * 65 + db * 32 + acc_row(r, lane)] = acc[db][r] * mul;
-    // same-wave LDS RAW is ordered; mul may differ per lane (1/l), applied before the transpose
-    for (int row = 0; row < 32; ++row) {
-        if (row < nvalid_rows) gout[(int64_t)(row0 + row) * ld + lane] = from_f32<T>(slab[row * 65 + lane]);
+    // same-wave LDS RAW is ordered; mul may differ per lane (1/l), applied before the transpose.
+    // Rows leave as 16-byte vectors: lane -> row it*8 + lane/8, columns (lane&7)*8 .. +8
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c0 = (lane & 7) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = slab[row * 65 + c0 + e];
+        if (row < nvalid_rows) store8<T>(gout + (int64_t)(row0 + row) * ld + c0, v);
     }
 }
 

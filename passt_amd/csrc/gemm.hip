@@ -22,30 +22,6 @@ static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
 
 
 
-// 8 consecutive elements <-> 8 floats (16-byte vectors; N % 8 == 0 is an API precondition)
-template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
-    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-}
-template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-    *(bf16x8*)p = o;
-}
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
-    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
-}
-template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
-    const bf16x8 a = *(const bf16x8*)p;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
-}
-
 // Shared epilogue: the 2x2 MFMA accumulators of this wave (64x64 outputs at rows m0 + wr*64, columns
 // n0 + wc*64) -> per-wave LDS slab -> 8-wide row vectors with the fused epilogue math.
 // vmcnt counts stores as well as loads on CDNA and retires in order, so a wait for ANY load also waits for
@@ -115,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
             } else if constexpr (EPI == PA_EPI_GELU) {
                 float g[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(to_f32<T>(from_f32<T>(v[it][e])));
+                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(v[it][e]);   // of the f32 value (the reference applies GELU before rounding too)
                 store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
                 store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g);
             } else if constexpr (EPI == PA_EPI_RESID) {
@@ -890,13 +866,30 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, i
     if (lane == 0) out[row] = (accumulate ? out[row] : 0.f) + s;
 }
 
-__global__ void colsum_f32_kernel(const float* __restrict__ in, int R, int C, int ld,
-                                  float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += in[(int64_t)r * ld + c];
-    out[c] = (accumulate ? out[c] : 0.f) + s;
+// out[c] (+)= sum_r in[r][c]; block = 64 columns x 4 row groups, 4 independent accumulators per thread so
+// several loads are in flight (the loop is latency-, not bandwidth-bound)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, int R, int C, int ld,
+                                                         float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = ry;
+        for (; r + 12 < R; r += 16) {
+            s0 += in[(int64_t)r * ld + c];
+            s1 += in[(int64_t)(r + 4) * ld + c];
+            s2 += in[(int64_t)(r + 8) * ld + c];
+            s3 += in[(int64_t)(r + 12) * ld + c];
+        }
+        for (; r < R; r += 4) s0 += in[(int64_t)r * ld + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const float s = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        out[c] = (accumulate ? out[c] : 0.f) + s;
+    }
 }
 
 }  // namespace pa
@@ -969,7 +962,7 @@ extern "C" int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float*
 extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate,
                              void* stream) {
     if (!in || !out || R <= 0 || C <= 0) return PA_EINVAL;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out, accumulate);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out, accumulate);
     return check_launch();
 }
 
@@ -985,14 +978,14 @@ extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     return PA_EINVAL;
 }
 
-extern "C" int64_t pa_colsum_ws_floats(int R, int C) { return (int64_t)std::min<int64_t>(64, cdiv(R, 256)) * C; }
+extern "C" int64_t pa_colsum_ws_floats(int R, int C) { return (int64_t)std::min<int64_t>(32, cdiv(R, 256)) * C; }
 
 extern "C" int pa_colsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate, float* ws,
                          void* stream) {
     if (!in || !out || !ws || R <= 0 || C <= 0) return PA_EINVAL;
     const size_t es = dtype == PA_BF16 ? 2 : 4;
     if ((ld * es) % 16 || C % 8) return PA_EUNSUPPORTED;
-    const int rblocks = (int)std::min<int64_t>(64, cdiv(R, 256));
+    const int rblocks = (int)std::min<int64_t>(32, cdiv(R, 256));
     const int rpb = (int)cdiv(R, rblocks);
     dim3 grid((unsigned)cdiv(C, 64), (unsigned)rblocks);
     hipStream_t st = (hipStream_t)stream;
@@ -1001,6 +994,6 @@ extern "C" int pa_colsum(const void* in, int dtype, int R, int C, int ld, float*
     else return PA_EINVAL;
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, ws, rblocks, C, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, ws, rblocks, C, C, out, accumulate);
     return check_launch();
 }

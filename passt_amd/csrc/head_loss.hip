@@ -133,15 +133,20 @@ __global__ __launch_bounds__(256) void head_pre_bwd_kernel(const float* __restri
     for (int64_t i = tid; i < rest / 4; i += 256) z[i] = make_float4(0, 0, 0, 0);
 }
 
-// y[b][c] = x[b] . W[c] + bias[c] ; one wave per (c), loop over b
-__global__ __launch_bounds__(64) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int C, int D) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += x[(int64_t)b * D + d] * W[(int64_t)c * D + d];
-        s = wave_sum(s);
-        if (lane == 0) y[(int64_t)b * C + c] = s + (bias ? bias[c] : 0.f);
+// y[b][c] = x[b] . W[c] + bias[c]; one workgroup per class c, the 4 waves split the batch rows
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int C, int D) {
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* w = W + (int64_t)c * D;
+    const float bc = bias ? bias[c] : 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float* xr = x + (int64_t)b * D;
+        float s0 = 0.f, s1 = 0.f;
+        int d = lane;
+        for (; d + 64 < D; d += 128) { s0 += xr[d] * w[d]; s1 += xr[d + 64] * w[d + 64]; }
+        for (; d < D; d += 64) s0 += xr[d] * w[d];
+        const float s = wave_sum(s0 + s1);
+        if (lane == 0) y[(int64_t)b * C + c] = s + bc;
     }
 }
 __global__ void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
@@ -218,7 +223,7 @@ extern "C" int pa_head_pre_bwd(const float* dhn, const float* dfeat, const float
 
 extern "C" int pa_linear_f32_fwd(const float* x, const float* W, const float* b, float* y, int B, int C, int D, void* stream) {
     if (!x || !W || !y || B <= 0 || C <= 0 || D <= 0) return PA_EINVAL;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, x, W, b, y, B, C, D);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, C, D);
     return check_launch();
 }
 

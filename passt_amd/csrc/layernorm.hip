@@ -152,9 +152,18 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     __shared__ float red[16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + cx;   // index into [2][D]
-    float s = 0.f;
-    if (k < 2 * D)
-        for (int b = ry; b < nblk; b += 16) s += ws[(int64_t)b * 2 * D + k];
+    float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < 2 * D) {
+        int b = ry;
+        for (; b + 48 < nblk; b += 64) {          // 4 loads in flight
+            s += ws[(int64_t)b * 2 * D + k];
+            s1 += ws[(int64_t)(b + 16) * 2 * D + k];
+            s2 += ws[(int64_t)(b + 32) * 2 * D + k];
+            s3 += ws[(int64_t)(b + 48) * 2 * D + k];
+        }
+        for (; b < nblk; b += 16) s += ws[(int64_t)b * 2 * D + k];
+    }
+    s = (s + s1) + (s2 + s3);
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && k < 2 * D) {

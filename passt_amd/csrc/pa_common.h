@@ -46,26 +46,54 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- exact (erf) GELU, nn.GELU default approximate='none' (models/passt.py:286) -------------------
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. f32 round-off class) on hardware rcp/exp:
-// ~12 VALU ops instead of libm erff's branchy ~30, and GELU' reuses the SAME exponential for the pdf.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
-    const float z = fabsf(x) * 0.70710678118654752440f;           // |x| / sqrt(2)
-    ex = __expf(-z * z);                                          // exp(-x^2 / 2)
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t +
-                        0.254829592f) * t;
-    const float erf_abs = 1.0f - poly * ex;                       // erf(|x|/sqrt2)
-    cdf = 0.5f + copysignf(0.5f * erf_abs, x);
+// Phi(x) through erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7: f32 round-off class) on the
+// hardware v_rcp_f32 / v_exp_f32 (no IEEE division, no libm erff):
+//   q(x) = 0.5 * poly(t) * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)      ( = 1 - Phi(|x|) )
+//   gelu(x)  = relu(x) - |x| q          gelu'(x) = Phi(x) + x phi(x),  Phi(x) = x >= 0 ? 1 - q : q
+// ~14 / ~18 VALU ops per element; the GELU' pdf reuses the same exponential.
+__device__ __forceinline__ float gelu_q(float ax, float& ex) {
+    ex = __builtin_amdgcn_exp2f(ax * ax * -0.72134752044448170368f);          // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    return poly * t * ex;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
-    float cdf, ex;
-    gelu_parts(x, cdf, ex);
-    return x * cdf;
+    float ex;
+    const float ax = fabsf(x);
+    return fmaf(-ax, gelu_q(ax, ex), fmaxf(x, 0.0f));
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    float cdf, ex;
-    gelu_parts(x, cdf, ex);
-    return cdf + x * 0.39894228040143267794f * ex;
+    float ex;
+    const float q = gelu_q(fabsf(x), ex);
+    const float cdf = x >= 0.0f ? 1.0f - q : q;
+    return fmaf(x * 0.39894228040143267794f, ex, cdf);
+}
+
+// ---- 8 consecutive elements <-> 8 floats (16-byte vectors; N % 8 == 0 is an API precondition)
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *(bf16x8*)p = o;
+}
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+    const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
 }
 
 // ---- XCD-aware, bijective block-id remap (guide T1): consecutive logical ids share an XCD ----
