@@ -46,45 +46,53 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): bias landed; nothing below waits on it again
     }
+    // auxiliary inputs (residual / pre-activation) of pass i+1 are requested before pass i is processed, so
+    // their HBM latency hides under the slab transpose and the stores of the previous pass
+    constexpr bool HAS_AUX = (EPI == PA_EPI_RESID || EPI == PA_EPI_DGELU);
+    float x[2][4][8];
+    auto pass_row = [&](int i, int it) {
+        const int m = m0 + wr * (TM * 32) + i * 32 + it * 8 + erow;
+        return (m < a.M && colok) ? m : -1;
+    };
+    auto load_aux = [&](int slot, int i) {
+        if constexpr (HAS_AUX) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = pass_row(i, it);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[slot][it][e] = 0.f;
+                if (m >= 0) {
+                    if constexpr (EPI == PA_EPI_RESID) {
+                        const int64_t rrow = a.row_mod > 0 ? m % a.row_mod : m;
+                        load8<float>(a.resid + rrow * a.ldr + ncol, x[slot][it]);
+                    } else {
+                        load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, x[slot][it]);
+                    }
+                }
+            }
+        }
+    };
+    load_aux(0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) load_aux((i + 1) & 1, i + 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[acc_row(r, lane) * 68 + j * 32 + (lane & 31)] = acc[i][j][r];
         // same-wave LDS RAW: the LDS queue is in order per wave; no barrier needed
-        float v[4][8], x[4][8];
-        int mrow[4];
+        float v[4][8];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + erow;
-            const int m = m0 + wr * (TM * 32) + i * 32 + row;
-            mrow[it] = (m < a.M && colok) ? m : -1;
             const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
             const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[it][e] = lo[e] + bias8[e]; v[it][4 + e] = hi[e] + bias8[4 + e]; }
         }
-        // ---- all auxiliary loads of this pass ----
-        if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_DGELU) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
-                if (mrow[it] >= 0) {
-                    if constexpr (EPI == PA_EPI_RESID) {
-                        const int64_t rrow = a.row_mod > 0 ? mrow[it] % a.row_mod : mrow[it];
-                        load8<float>(a.resid + rrow * a.ldr + ncol, x[it]);
-                    } else {
-                        load8<T>((const T*)a.aux + (int64_t)mrow[it] * a.ldaux + ncol, x[it]);
-                    }
-                }
-            }
-        }
-        // ---- math + all stores of this pass ----
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int m = mrow[it];
+            const int m = pass_row(i, it);
             if (m < 0) continue;
             if constexpr (EPI == PA_EPI_STORE) {
                 store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
@@ -98,11 +106,11 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
                 int64_t orow = m;
                 if (a.row_mod > 0) orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + m % a.row_mod;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[it][e] += x[it][e];
+                for (int e = 0; e < 8; ++e) v[it][e] += x[i & 1][it][e];
                 store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v[it]);
             } else if constexpr (EPI == PA_EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[it][e] *= gelu_erf_grad(x[it][e]);
+                for (int e = 0; e < 8; ++e) v[it][e] *= gelu_erf_grad(x[i & 1][it][e]);
                 store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
             } else {  // PA_EPI_PARTIAL
                 store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v[it]);
