@@ -427,7 +427,7 @@ static int pick_nt_variant(int M, int N, int K) {
         {1, 128, 128, 512, 750.f, 930.f},
         {8, 128, 256, 256, 650.f, 1000.f},
         {7, 192, 256, 256, 780.f, 1250.f},
-        {6, 256, 256, 256, 760.f, 1150.f},
+        {6, 256, 256, 256, 800.f, 1150.f},
     };
     int best = 1;
     double best_cost = 1e30;
