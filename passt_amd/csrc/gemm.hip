@@ -361,23 +361,19 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     __builtin_amdgcn_s_barrier();                          // tile 0 complete for everyone
     if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
 
-    typename Frag<T>::type fa[2][TM], fb[2][2];            // fragment double buffer (phase parity)
     for (int t = 0; t < nsteps; ++t) {
         const char* sA = smem + (t & 1) * STAGE_BYTES;
         const char* sB = sA + A_BYTES;
         const bool more = t + 1 < nsteps;
-        auto read_frags = [&](int slot, int ph) {
-            const int coff = ((ph * 2 + half) ^ rsw) << 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[slot][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
-        };
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-            // ---------------- L segment: only phase 0 still reads here (a new K-tile has just been published);
-            // phases 1-3 were prefetched inside the previous M segment ----------------
-            if (ph == 0) read_frags(0, 0);
+            // ---------------- L segment ----------------
+            typename Frag<T>::type fa[TM], fb[2];
+            const int coff = ((ph * 2 + half) ^ rsw) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
             if (more) {
                 if (ph == 0) dmaA((t + 1) & 1, t + 1);
                 if (ph == 1) dmaB((t + 1) & 1, t + 1);
@@ -386,13 +382,12 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // ---------------- M segment: 2*TM MFMAs; the next phase's ds_reads ride in the issue slots between them
+            // ---------------- M segment ----------------
             __builtin_amdgcn_s_setprio(1);
-            if (ph < 3) read_frags((ph + 1) & 1, ph + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[ph & 1][i], fb[ph & 1][j]);
+                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
             __builtin_amdgcn_s_setprio(0);
             if (ph == 3 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -709,21 +704,18 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
 
-    bf16x8 fa[2][TM], fb[2][2];                             // fragment double buffer (phase parity)
     for (int t = 0; t < nsteps; ++t) {
         const char* sA = smem + (t & 1) * STAGE_BYTES;
         const char* sB = sA + OP_BYTES;
         const bool more = t + 1 < nsteps;
-        auto read_frags = [&](int slot, int ph) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[slot][i] = tn2_frag(sA, ph, wr * 128 + i * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[slot][j] = tn2_frag(sB, ph, wc * 64 + j * 32, lane);
-        };
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-            // ---------------- L segment (phase 0 reads its 16-token fragments here; 1-3 were prefetched) -------
-            if (ph == 0) read_frags(0, 0);
+            // ---------------- L segment: fragments of 16 tokens ----------------
+            bf16x8 fa[TM], fb[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = tn2_frag(sA, ph, wr * 128 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tn2_frag(sB, ph, wc * 64 + j * 32, lane);
             if (more) {
                 if (ph == 0) dmaA((t + 1) & 1, t + 1);
                 if (ph == 1) dmaB((t + 1) & 1, t + 1);
@@ -737,11 +729,10 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
             __builtin_amdgcn_s_barrier();
             // ---------------- M segment ----------------
             __builtin_amdgcn_s_setprio(1);
-            if (ph < 3) read_frags((ph + 1) & 1, ph + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[ph & 1][i], fb[ph & 1][j]);
+                for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
             __builtin_amdgcn_s_setprio(0);
             if (ph == 3 && wr == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
