@@ -176,9 +176,21 @@ def main():
                 tot_flop += fl
                 n += len(recs)
             achieved = tot_flop / tot_ms / 1e9
+            # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
+            # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
+            # over this very command and committed (tools_gemm_traffic.py -> profiles/r01_gemm_traffic.json)
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            if os.path.isfile(tpath) and args.batch == 64 and args.precision == "bf16":
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "pa::gemm_nt_kernel<bf16,*> (all epilogues; 2*M*N*K algorithmic FLOPs per launch)",
+                               "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                               "algorithmic_flop_per_launch": round(tot_flop / n),
+                               "kernel": "GEMM family pa::gemm_nt_stagger_kernel / gemm_nt_kernel / gemm_tn_stagger_kernel <bf16> "
+                                         "(all epilogues + weight gradients; 2*M*N*K algorithmic FLOPs per launch)",
                                "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
                                "gemm_time_share_of_step": round(tot_ms / (1e3 * elapsed), 3),
                                "per_epilogue": per_kind}
