@@ -195,3 +195,76 @@ def test_module_contract():
     assert torch.equal(a, a2)
     with pytest.raises(RuntimeError):
         passt_amd.get_model(arch="nope", pretrained=False)
+
+
+# ---- the remaining BASELINE.json configs, at full width and reduced depth/batch, vs the oracle ----------
+CONFIG_CASES = {
+    # configs[3]: ViT-L-like 1024/16 heads, unstructured patchout 400 (N = 1188 - 400 + 2 = 790)
+    "c4_1024w_u400": dict(cfg=O.make_cfg(embed_dim=1024, depth=2, num_heads=16, num_classes=527, u_patchout=400),
+                          B=2, T=998, seed=71, torch_seed=5),
+    # configs[3] companion: the reference's real passt_l width (768/12 heads), u_patchout
+    "c4_passt_l_768": dict(cfg=O.make_cfg(embed_dim=768, depth=2, num_heads=12, num_classes=527, u_patchout=400),
+                           B=2, T=998, seed=72, torch_seed=6),
+    # configs[4]: ESC-50 fine-tune, 5 s clips -> 500 frames -> 49 time patches < 99 => random pos-embed offset
+    "c5_esc50": dict(cfg=O.make_cfg(embed_dim=768, depth=2, num_heads=12, num_classes=50, s_patchout_t=10,
+                                    s_patchout_f=3), B=3, T=500, seed=73, torch_seed=7),
+    # configs[1]/[2] token geometry: s_patchout_t=40, f=4 => 474 tokens
+    "c2_474_tokens": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, num_classes=527, s_patchout_t=40,
+                                         s_patchout_f=4), B=2, T=998, seed=74, torch_seed=8),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIG_CASES))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_baseline_config_shapes_vs_oracle(name, precision):
+    case = dict(CONFIG_CASES[name], training=True)
+    cfg = case["cfg"]
+    m = build(case, precision).train()
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]), requires_grad=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(case["torch_seed"])
+        lo, fo = O.passt_forward(sd, torch.from_numpy(x), cfg, training=True)
+        O.bce_loss(lo, torch.from_numpy(y)).backward()
+        torch.manual_seed(case["torch_seed"])
+        lg, fg = m(xg)
+        torch.nn.functional.binary_cross_entropy_with_logits(lg, yg, reduction="none").mean().backward()
+    lim = 1e-3 if precision == "fp32" else 4e-2
+    e_l, e_f = rel(lg.detach().cpu(), lo.detach()), rel(fg.detach().cpu(), fo.detach())
+    assert e_l < lim and e_f < lim, (e_l, e_f)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if k.startswith("head_dist"):
+            continue
+        e = rel(p.grad.cpu(), sd[k].grad)
+        worst = max(worst, e)
+        assert e < (1e-3 if precision == "fp32" else 8e-2), (k, e)
+    record(f"{name}[{precision}]", logits=e_l, features=e_f, worst_grad=worst)
+
+
+def test_train_step_driver_matches_autograd_path():
+    """passt_amd.train.TrainStep (explicit backward, flat buffers, fused AdamW) == autograd path + torch AdamW."""
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=901)
+    m1, m2 = build(case, "fp32").train(), build(case, "fp32").train()
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    opt = torch.optim.AdamW([p for n, p in m1.named_parameters() if not n.startswith("head_dist")], lr=1e-3,
+                            weight_decay=1e-2)
+    ts = TrainStep(m2, None, lr=1e-3, weight_decay=1e-2, use_mixup=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(3):
+            torch.manual_seed(50 + step)
+            lg, _ = m1(xg)
+            loss1 = torch.nn.functional.binary_cross_entropy_with_logits(lg, yg, reduction="none").mean()
+            opt.zero_grad()
+            loss1.backward()
+            opt.step()
+            torch.manual_seed(50 + step)
+            loss2 = ts.step(xg, yg)
+            assert abs(loss1.item() - loss2.item()) < 1e-5, step
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert rel(p2.detach().cpu(), p1.detach().cpu()) < 2e-4, k
