@@ -242,6 +242,30 @@ def _wgrad_pair(dY, X, dW, db, dt, scratch, accumulate):
         ops.colsum(dY, db, accumulate=accumulate)
 
 
+class _SideStream:
+    """Weight-gradient GEMMs and bias-gradient reductions are off the input-gradient critical path: they run
+    on a second HIP stream so their workgroups interleave with the dgrad / LayerNorm / attention kernels
+    (fills tile-quantisation tails, overlaps epilogue write bursts with compute).  ``fork(*tensors)`` orders the
+    side stream after everything enqueued so far on the main stream; ``join()`` makes the main stream wait."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream(device=device) if self.enabled else None
+
+    def fork(self, *tensors):
+        if not self.enabled:
+            return torch.cuda.stream(None)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)          # caching-allocator safety across streams
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     """Backward of passt_forward.  ``grads``: dict param-name -> f32 tensor to OVERWRITE.
     ``on_block_done(i)`` is called after block i's parameter gradients are enqueued (i = depth for the
@@ -253,6 +277,17 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     M = B * Ntok
     scratch = model._scratch
     g = grads
+    side = scratch.get("side")
+    if side is None:
+        side = scratch["side"] = _SideStream(dlogits.device, enabled=getattr(model, "overlap_wgrad", True))
+
+    def wgrad_async(dY, X, dW, db, done=None):
+        """dW, db on the side stream; optionally report block completion from there (DDP bucket launch)."""
+        with side.fork(dY, X):
+            _wgrad_pair(dY, X, dW, db, dt, scratch, False)
+            if done is not None and on_block_done:
+                on_block_done(done)
+
     # head: logits = hn W^T + b ; hn = LN_1e-5(feat) ; feat = mean of the two normed prefix tokens
     dhn = ops.linear_f32_bwd(dlogits.contiguous(), ctx["hn"], model.head[1].weight, g["head.1.weight"],
                              g["head.1.bias"])
@@ -270,35 +305,34 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         pfx = f"blocks.{i}."
         xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = ctx["saved"][i]
         # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        _wgrad_pair(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"], dt, scratch, False)
+        wgrad_async(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"])
         d_pre = torch.empty_like(h_pre)
         ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre)
-        _wgrad_pair(d_pre, ln2, g[pfx + "mlp.fc1.weight"], g[pfx + "mlp.fc1.bias"], dt, scratch, False)
+        wgrad_async(d_pre, ln2, g[pfx + "mlp.fc1.weight"], g[pfx + "mlp.fc1.bias"])
         d_ln2 = torch.empty_like(ln2)
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
         del d_pre
         dx, dx_lp = ops.layernorm_bwd(d_ln2, x_mid, blk.norm2.weight, mean2, rstd2, dx, g[pfx + "norm2.weight"],
                                       g[pfx + "norm2.bias"], True)
         # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-        _wgrad_pair(dx_lp, att, g[pfx + "attn.proj.weight"], g[pfx + "attn.proj.bias"], dt, scratch, False)
+        wgrad_async(dx_lp, att, g[pfx + "attn.proj.weight"], g[pfx + "attn.proj.bias"])
         d_att = torch.empty_like(att)
         ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
         d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"])
-        _wgrad_pair(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], dt, scratch, False)
         d_ln1 = torch.empty_like(ln1)
         ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)
         dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dx, g[pfx + "norm1.weight"],
                                       g[pfx + "norm1.bias"], i > 0)
-        if on_block_done:
-            on_block_done(i)
+        # last weight gradient of the block; the side stream (ordered after the LayerNorm gradients above)
+        # then reports the block complete, so its all-reduce bucket starts without stalling the main stream
+        wgrad_async(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], done=i)
     # ---- patch embedding / positional parameters / prefix tokens
     Tpe, Fpe = model.time_new_pos_embed.shape[-1], model.freq_new_pos_embed.shape[-2]
     dpatch = ops.patch_bwd(dx.view(B, Ntok, D), ctx["pf"], ctx["pt"], ctx["toff"], Tpe, Fpe, g["cls_token"],
                            g["dist_token"], g["new_pos_embed"], g["patch_embed.proj.bias"],
                            g["time_new_pos_embed"], g["freq_new_pos_embed"], dt)
-    _wgrad_pair(dpatch, ctx["cols"], g["patch_embed.proj.weight"], None, dt, scratch, False)
-    if on_block_done:
-        on_block_done(-1)
+    wgrad_async(dpatch, ctx["cols"], g["patch_embed.proj.weight"], None, done=-1)
+    side.join()
 
 
 class _PasstFunction(torch.autograd.Function):
