@@ -226,6 +226,11 @@ int pa_head_pre_bwd(const float* dhn, const float* dfeat, const float* x, const 
 int pa_bce_fwd_bwd(const float* logits, const float* target, int B, int C, float grad_scale,
                    float* loss, float* dlogits, float* ws, void* stream);
 
+/* ESC-50 caller (ex_esc50.py:159-165): loss[0] = mean_b [ lam_b CE(z_b, target_b) + (1-lam_b) CE(z_b, target2_b) ];
+ * target2 / lam may be NULL (plain cross entropy).  Targets are class indices.  ws: >= B floats. */
+int pa_ce_mixup_fwd_bwd(const float* logits, const int32_t* target, const int32_t* target2, const float* lam,
+                        int B, int C, float grad_scale, float* loss, float* dlogits, float* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training-step glue of the caller ("next" rows)
  * ------------------------------------------------------------------------------------------ */

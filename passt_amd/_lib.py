@@ -59,6 +59,7 @@ SIGNATURES = {
     "pa_linear_f32_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "pa_head_pre_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "pa_bce_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+    "pa_ce_mixup_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "pa_mixup": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "pa_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "pa_sgd": (i32, [vp, vp, i64, f32, vp]),

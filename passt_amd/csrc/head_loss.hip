@@ -197,6 +197,35 @@ __global__ __launch_bounds__(256) void bce_final_kernel(const float* __restrict_
     if (threadIdx.x == 0) loss[0] = s * inv_n;
 }
 
+// Cross-entropy with mixup targets (ex_esc50.py:159-165): one wave per row.
+//   loss_b = lam_b * CE(z_b, y_b) + (1 - lam_b) * CE(z_b, y2_b),  CE(z, y) = logsumexp(z) - z[y]
+//   d loss_b / d z = softmax(z_b) - lam_b * onehot(y_b) - (1 - lam_b) * onehot(y2_b)
+__global__ __launch_bounds__(256) void ce_mixup_kernel(const float* __restrict__ z, const int32_t* __restrict__ y,
+                                                       const int32_t* __restrict__ y2, const float* __restrict__ lam,
+                                                       int B, int C, float gscale, float* __restrict__ dz,
+                                                       float* __restrict__ row_loss) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* zr = z + (int64_t)b * C;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, zr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(zr[c] - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    const int t1 = y[b], t2 = y2 ? y2[b] : t1;
+    const float l1 = lam ? lam[b] : 1.0f;
+    if (lane == 0) row_loss[b] = l1 * (lse - zr[t1]) + (1.0f - l1) * (lse - zr[t2]);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < C; c += 64) {
+        float g = __expf(zr[c] - m) * inv;
+        if (c == t1) g -= l1;
+        if (c == t2) g -= 1.0f - l1;
+        dz[(int64_t)b * C + c] = g * gscale;
+    }
+}
+
 }  // namespace pa
 
 using namespace pa;
@@ -248,5 +277,17 @@ extern "C" int pa_bce_fwd_bwd(const float* logits, const float* target, int B, i
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, ws, nblk, 1.0f / (float)n, loss);
+    return check_launch();
+}
+
+extern "C" int pa_ce_mixup_fwd_bwd(const float* logits, const int32_t* target, const int32_t* target2, const float* lam,
+                                   int B, int C, float grad_scale, float* loss, float* dlogits, float* ws, void* stream) {
+    if (!logits || !target || !loss || !dlogits || !ws || B <= 0 || C <= 0) return PA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_mixup_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, st, logits, target, target2, lam, B, C,
+                       grad_scale / (float)B, dlogits, ws);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, ws, B, 1.0f / (float)B, loss);
     return check_launch();
 }

@@ -350,6 +350,17 @@ def bce_fwd_bwd(logits, target, grad_scale=1.0):
     return loss, dlogits
 
 
+def ce_mixup_fwd_bwd(logits, target_i32, target2_i32=None, lam=None, grad_scale=1.0):
+    """ESC-50 loss (ex_esc50.py:159-165); targets are int32 class indices."""
+    B, Cc = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits)
+    ws = torch.empty(max(B, 1), device=logits.device, dtype=torch.float32)
+    check(_lib.load().pa_ce_mixup_fwd_bwd(_p(logits), _p(target_i32), _p(target2_i32), _p(lam), B, Cc, grad_scale,
+                                          _p(loss), _p(dlogits), _p(ws), _stream()), "pa_ce_mixup_fwd_bwd")
+    return loss, dlogits
+
+
 # ---- caller glue -----------------------------------------------------------------------------
 def mixup(x, perm_i32, lam):
     B = x.shape[0]

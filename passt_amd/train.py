@@ -17,10 +17,12 @@ from .passt import passt_backward, passt_forward
 
 class TrainStep:
     def __init__(self, net, mel=None, lr=2e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, optimizer="adamw",
-                 mixup_alpha=0.3, use_mixup=True, process_group=None):
+                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce"):
         self.net, self.mel = net, mel
         self.lr, self.wd, self.betas, self.eps, self.optimizer = lr, weight_decay, betas, eps, optimizer
         self.mixup_alpha, self.use_mixup = mixup_alpha, use_mixup
+        assert loss in ("bce", "ce")      # bce: ex_audioset.py:181-186 ; ce: ex_esc50.py:159-165 (class-index targets)
+        self.loss = loss
         dev = next(net.parameters()).device
         names = net._grad_names
         self.named = [(n, p) for n, p in net.named_parameters() if n in names]
@@ -60,9 +62,18 @@ class TrainStep:
             perm_d = perm.to(torch.int32).to(x.device, non_blocking=True)
             lam_d = torch.from_numpy(lam).to(x.device, non_blocking=True)
             x = ops.mixup(x, perm_d, lam_d)
-            y = ops.mixup(y, perm_d, lam_d)
+            if self.loss == "bce":
+                y = ops.mixup(y, perm_d, lam_d)
         logits, feat, ctx = passt_forward(net, x, save=True)
-        loss, dlogits = ops.bce_fwd_bwd(logits, y, grad_scale=1.0 / self.reducer.world)
+        gs = 1.0 / self.reducer.world
+        if self.loss == "bce":
+            loss, dlogits = ops.bce_fwd_bwd(logits, y, grad_scale=gs)
+        else:
+            y32 = y.to(torch.int32)
+            if self.use_mixup:
+                loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, y32[perm_d.long()].contiguous(), lam_d, grad_scale=gs)
+            else:
+                loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, grad_scale=gs)
         passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self.reducer.on_block_done)
         self.reducer.wait()
         self.t += 1

@@ -151,3 +151,17 @@ def test_host_index_logic_matches_reference_order():
             gf, gt = gf[d["idx_u"]], gt[d["idx_u"]]
         pf, pt = kept_patches(Fd, T_eff, it, if_, iu)
         assert np.array_equal(pf, gf.numpy()) and np.array_equal(pt, gt.numpy())
+
+
+def test_reference_module_paths_resolve_to_this_implementation():
+    """`models.passt` / `models.preprocess` (the paths ex_audioset.py:61-70 configures) are served by passt_amd."""
+    import importlib
+    import sys
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    mp = importlib.import_module("models.passt")
+    mpre = importlib.import_module("models.preprocess")
+    import passt_amd
+    assert mp.get_model is passt_amd.passt.get_model and mp.PaSST is passt_amd.PaSST
+    assert mpre.AugmentMelSTFT is passt_amd.AugmentMelSTFT
+    assert mp.get_model_passt is mp.get_model

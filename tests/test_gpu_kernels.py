@@ -340,3 +340,25 @@ def test_mixup_and_optimizers():
     q = p0.clone().to(DEV)
     ops.sgd(q, g.to(DEV), 0.1)
     assert rel_err(q, p0 - 0.1 * g) < 1e-6
+
+
+def test_ce_mixup_loss():
+    """ESC-50 caller loss (ex_esc50.py:159-165) and its logits gradient."""
+    import torch.nn.functional as Fnn
+    B, C = 12, 50
+    z = rnd(B, C, seed=60, scale=3.0)
+    y = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(61))
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(62))
+    lam = torch.rand(B, generator=torch.Generator().manual_seed(63)) * 0.5 + 0.5
+    zr = z.double().requires_grad_(True)
+    ref = (Fnn.cross_entropy(zr, y, reduction="none") * lam.double()
+           + Fnn.cross_entropy(zr, y[perm], reduction="none") * (1 - lam.double())).mean()
+    ref.backward()
+    loss, dz = ops.ce_mixup_fwd_bwd(z.to(DEV), y.to(torch.int32).to(DEV), y[perm].to(torch.int32).to(DEV), lam.to(DEV))
+    assert abs(float(loss) - float(ref.detach())) < 1e-5
+    assert rel_err(dz, zr.grad) < 1e-5
+    zr.grad = None
+    ref2 = Fnn.cross_entropy(zr, y)
+    ref2.backward()
+    loss2, dz2 = ops.ce_mixup_fwd_bwd(z.to(DEV), y.to(torch.int32).to(DEV))
+    assert abs(float(loss2) - float(ref2.detach())) < 1e-5 and rel_err(dz2, zr.grad) < 1e-5
