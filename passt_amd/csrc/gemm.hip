@@ -450,6 +450,7 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
         switch (v) {
             case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
             case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
+            case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2>(a, st);   // 192x128, 4 waves (96x64 each), 80 KiB: 2 workgroups / CU
             case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
             case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
             case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split
