@@ -278,8 +278,10 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     scratch = model._scratch
     g = grads
     side = scratch.get("side")
+    if side is not None and side.enabled != bool(getattr(model, "overlap_wgrad", False)):
+        side = None
     if side is None:
-        side = scratch["side"] = _SideStream(dlogits.device, enabled=getattr(model, "overlap_wgrad", True))
+        side = scratch["side"] = _SideStream(dlogits.device, enabled=getattr(model, "overlap_wgrad", False))
 
     def wgrad_async(dY, X, dW, db, done=None):
         """dW, db on the side stream; optionally report block completion from there (DDP bucket launch)."""
@@ -404,6 +406,9 @@ class PaSST(nn.Module):
                                   nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity())
         self.head_dist = nn.Linear(self.embed_dim, self.num_classes) if num_classes > 0 else nn.Identity()
         self.precision = None          # None: follow torch.autocast; or "fp32" / "bf16"
+        # opt-in: run weight/bias-gradient kernels on a second stream (+2.4 % step throughput measured on MI355X);
+        # off by default so that every kernel runs alone and per-kernel timings (bench.py roofline, rocprof) are exact
+        self.overlap_wgrad = False
         self.init_weights(weight_init)
         self._reset_runtime()
 
