@@ -147,6 +147,12 @@ int pa_gemm_nt(const pa_gemm_args* a, void* stream);
  * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over
  * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic). */
 int pa_gemm_tn(const pa_gemm_args* a, void* stream);
+/* Row gather / scatter and strided zero fill (prefix-token path of the last block):
+ * gather: out[i] = in[idx[i]]; scatter: out[idx[i]] = in[i]; rows of row_bytes bytes (multiple of 4). */
+int pa_gather_rows(const void* in, const int32_t* idx, int n_idx, int64_t row_bytes, void* out, void* stream);
+int pa_scatter_rows(const void* in, const int32_t* idx, int n_idx, int64_t row_bytes, void* out, void* stream);
+/* zero `rows` rows of width_bytes at pitch_bytes */
+int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, int64_t rows, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_z partial[z][i], i < n */
 int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out, int accumulate,
                        void* stream);
@@ -166,12 +172,17 @@ int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumul
  * softmax((Q K^T) * scale) V per (batch, head), flash-style (scores never reach HBM), head_dim 64.
  * q/k/v are read in place from the qkv GEMM output [B*N][3*H*64] ([q|k|v] x head x 64, the
  * reshape of :345); o is written token-major [B*N][H*64] (the transpose+reshape of :358).
+ *
+ * nq (1..N): only the first nq queries of every sequence are produced -- N for a normal block; 2 for the LAST
+ * block, whose output is only ever read at the cls/dist rows (models/passt.py:570-574).  o, d_o, lse and delta are
+ * then COMPACT: o[(b*nq + q)][H*64], lse[(b*H + h)*nq + q].  K and V always span all N tokens.
  * ------------------------------------------------------------------------------------------ */
-int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                      float scale, int dtype, void* stream);
-/* dqkv[B*N][3*H*64] from do[B*N][H*64]; lse from the forward; delta: f32 workspace [B*H*N]. */
+/* dqkv[B*N][3*H*64] from d_o[B*nq][H*64]; lse from the forward; delta: f32 workspace [B*H*nq].  The K and V thirds
+ * of dqkv are written for all N tokens, the Q third only for rows q < nq (the caller zeroes the rest: pa_zero2d). */
 int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
-                     const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N,
+                     const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
                      float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

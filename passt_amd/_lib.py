@@ -49,8 +49,11 @@ SIGNATURES = {
     "pa_reduce_partials": (i32, [vp, i32, i64, vp, i32, vp]),
     "pa_rowsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "pa_colsum_f32": (i32, [vp, i32, i32, i32, vp, i32, vp]),
-    "pa_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, i32, vp]),
-    "pa_attention_bwd": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "pa_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "pa_attention_bwd": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "pa_gather_rows": (i32, [vp, vp, i32, i64, vp, vp]),
+    "pa_scatter_rows": (i32, [vp, vp, i32, i64, vp, vp]),
+    "pa_zero2d": (i32, [vp, i64, i64, i64, vp]),
     "pa_patch_gather": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "pa_patch_pos_table": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "pa_patch_bwd": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp]),

@@ -119,7 +119,7 @@ static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
-                                                       int ldo, float* __restrict__ lse, int H, int N, float scale) {
+                                                       int ldo, float* __restrict__ lse, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,17 +212,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
             }
     }
     __syncthreads();   // tiles are dead; reuse LDS for the transposed store
-    if (q0 < N) {
-        if (lane < 32 && q0 + lane < N) lse[(int64_t)bh * N + q0 + lane] = m_run * LN2 + __logf(l_run);   // natural log units
-        store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, 1.0f / l_run, o + (int64_t)b * N * ldo + h * HD,
-                        ldo, q0, min(32, N - q0), lane);
+    // only the first nq queries of every sequence are produced; o / lse are compact (nq rows per sequence)
+    if (q0 < nq) {
+        if (lane < 32 && q0 + lane < nq) lse[(int64_t)bh * nq + q0 + lane] = m_run * LN2 + __logf(l_run);   // natural log units
+        store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, 1.0f / l_run, o + (int64_t)b * nq * ldo + h * HD,
+                        ldo, q0, min(32, nq - q0), lane);
     }
 }
 
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]   (one wave per token row, all heads)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
-                                                         float* __restrict__ delta, int B, int H, int N) {
+                                                         float* __restrict__ delta, int B, int H, int N) {   // N = rows per sequence of o/d_o (nq)
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= (int64_t)B * N) return;
@@ -241,14 +242,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ d_o, int ldo,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
+                                                            T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int D = H * HD;
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
-    const T* dobase = d_o + (int64_t)b * N * ldo + h * HD;
+    const T* dobase = d_o + (int64_t)b * nq * ldo + h * HD;     // d_o / lse / delta: nq rows per sequence
     const int k0 = blockIdx.x * 128 + wave * 32;
     const int key = k0 + (lane & 31);
     const int krow = min(key, N - 1);
@@ -267,14 +268,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
     const float sl2 = scale * LOG2E;
 
-    const int ntiles = (N + TROWS - 1) / TROWS;
+    const int ntiles = (nq + TROWS - 1) / TROWS;               // only queries < nq carry a gradient
     constexpr int STAGE = 2 * Tile<T>::BYTES + 2 * TROWS * 4;   // Q tile, dO tile, lse[64], delta[64]
     auto stage = [&](int buf, int qt) {
         char* sb = smem + buf * STAGE;
         stage_tile<T>(sb, base, ldqkv, qt * TROWS, N, wave, lane);
-        stage_tile<T>(sb + Tile<T>::BYTES, dobase, ldo, qt * TROWS, N, wave, lane);
-        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), lse + (int64_t)bh * N, qt * TROWS, N, lane);
-        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, delta + (int64_t)bh * N, qt * TROWS, N, lane);
+        stage_tile<T>(sb + Tile<T>::BYTES, dobase, ldo, qt * TROWS, nq, wave, lane);
+        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), lse + (int64_t)bh * nq, qt * TROWS, nq, lane);
+        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, delta + (int64_t)bh * nq, qt * TROWS, nq, lane);
     };
     stage(0, 0);
     for (int qt = 0; qt < ntiles; ++qt) {
@@ -303,12 +304,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
                 sa[r] = p;                                   // P
                 dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;  // dS
             }
-            // queries beyond N exist only in the last tile (uniform branch); lanes whose own key is beyond
+            // queries beyond nq exist only in the last tile (uniform branch); lanes whose own key is beyond
             // N only produce their own, never stored, outputs and need no mask
-            if (qt == ntiles - 1 && (N & (TROWS - 1))) {
+            if (qt == ntiles - 1 && (nq & (TROWS - 1))) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (qt * TROWS + qb * 32 + acc_row(r, lane) >= N) { sa[r] = 0.f; dpa[r] = 0.f; }
+                    if (qt * TROWS + qb * 32 + acc_row(r, lane) >= nq) { sa[r] = 0.f; dpa[r] = 0.f; }
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
@@ -338,17 +339,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ d_o, int ldo,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          T* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
+                                                          T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
     const int D = H * HD;
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
-    const T* dobase = d_o + (int64_t)b * N * ldo + h * HD;
+    const T* dobase = d_o + (int64_t)b * nq * ldo + h * HD;     // d_o / lse / delta: nq rows per sequence
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int q = q0 + (lane & 31);
-    const int qrow = min(q, N - 1);
+    const int qrow = min(q, nq - 1);
 
     typename Frag<T>::type qf[Tile<T>::NFRAG], dof[Tile<T>::NFRAG];
 #pragma unroll
@@ -357,8 +358,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         qf[s] = *(const typename Frag<T>::type*)(base + (int64_t)qrow * ldqkv + off);
         dof[s] = *(const typename Frag<T>::type*)(dobase + (int64_t)qrow * ldo + off);
     }
-    const float lse2 = lse[(int64_t)bh * N + qrow] * LOG2E;
-    const float dlt = delta[(int64_t)bh * N + qrow];
+    const float lse2 = lse[(int64_t)bh * nq + qrow] * LOG2E;
+    const float dlt = delta[(int64_t)bh * nq + qrow];
     f32x16 dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -411,36 +412,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         }
     }
     __syncthreads();
-    if (q0 < N)
+    if (q0 < nq)
         store_rows_T<T>((float*)smem + wave * (32 * 65), dq, 1.0f, dqkv + (int64_t)b * N * lddqkv + h * HD,
-                        lddqkv, q0, min(32, N - q0), lane);
+                        lddqkv, q0, min(32, nq - q0), lane);
 }
 
 template <typename T> static size_t fwd_lds() { return std::max<size_t>(4 * Tile<T>::BYTES, SLAB_BYTES); }
 template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * (2 * Tile<T>::BYTES + 2 * TROWS * 4), SLAB_BYTES); }
 
 template <typename T>
-static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                            float scale, hipStream_t st) {
-    dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, scale);
+    dim3 grid((unsigned)cdiv(nq, 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, nq, scale);
     return check_launch();
 }
 
 template <typename T>
 static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo, const float* lse,
-                           float* delta, void* dqkv, int lddqkv, int B, int H, int N, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)cdiv((int64_t)B * N, 4)), dim3(256), 0, st,
-                       (const T*)o, (const T*)d_o, ldo, delta, B, H, N);
+                           float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)cdiv((int64_t)B * nq, 4)), dim3(256), 0, st,
+                       (const T*)o, (const T*)d_o, ldo, delta, B, H, nq);
     int rc = check_launch();
     if (rc) return rc;
     dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
-                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, scale);
+                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
-                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, scale);
+    dim3 gridq((unsigned)cdiv(nq, 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, gridq, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
+                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
     return check_launch();
 }
 
@@ -453,21 +455,21 @@ static bool attn_args_ok(int ld, int dtype) {
     return (ld * es) % 16 == 0;
 }
 
-extern "C" int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N,
+extern "C" int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                                 float scale, int dtype, void* stream) {
-    if (!qkv || !o || !lse || B <= 0 || H <= 0 || N <= 0) return PA_EINVAL;
+    if (!qkv || !o || !lse || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N) return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype)) return PA_EUNSUPPORTED;
-    if (dtype == PA_BF16) return attention_fwd_t<bf16>(qkv, ldqkv, o, ldo, lse, B, H, N, scale, (hipStream_t)stream);
-    if (dtype == PA_F32) return attention_fwd_t<float>(qkv, ldqkv, o, ldo, lse, B, H, N, scale, (hipStream_t)stream);
+    if (dtype == PA_BF16) return attention_fwd_t<bf16>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, (hipStream_t)stream);
+    if (dtype == PA_F32) return attention_fwd_t<float>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, (hipStream_t)stream);
     return PA_EINVAL;
 }
 
 extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
-                                const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N,
+                                const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
                                 float scale, int dtype, void* stream) {
-    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0) return PA_EINVAL;
+    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N) return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype) || !attn_args_ok(lddqkv, dtype)) return PA_EUNSUPPORTED;
-    if (dtype == PA_BF16) return attention_bwd_t<bf16>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, scale, (hipStream_t)stream);
-    if (dtype == PA_F32) return attention_bwd_t<float>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, scale, (hipStream_t)stream);
+    if (dtype == PA_BF16) return attention_bwd_t<bf16>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, (hipStream_t)stream);
+    if (dtype == PA_F32) return attention_bwd_t<float>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, (hipStream_t)stream);
     return PA_EINVAL;
 }

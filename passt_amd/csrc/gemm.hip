@@ -901,6 +901,19 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     }
 }
 
+// out[i][:] = in[idx[i]][:]   (row gather; one workgroup per output row, any element size via bytes)
+__global__ void gather_rows_kernel(const char* __restrict__ in, const int32_t* __restrict__ idx, int64_t row_bytes,
+                                   char* __restrict__ out, int scatter) {
+    const int i = blockIdx.x;
+    const char* src = scatter ? in + (int64_t)i * row_bytes : in + (int64_t)idx[i] * row_bytes;
+    char* dst = scatter ? out + (int64_t)idx[i] * row_bytes : out + (int64_t)i * row_bytes;
+    if ((row_bytes & 15) == 0) {
+        for (int64_t o = (int64_t)threadIdx.x * 16; o < row_bytes; o += (int64_t)blockDim.x * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+    } else {
+        for (int64_t o = (int64_t)threadIdx.x * 4; o < row_bytes; o += (int64_t)blockDim.x * 4) *(uint32_t*)(dst + o) = *(const uint32_t*)(src + o);
+    }
+}
+
 }  // namespace pa
 
 using namespace pa;
@@ -1005,4 +1018,26 @@ extern "C" int pa_colsum(const void* in, int dtype, int R, int C, int ld, float*
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, ws, rblocks, C, C, out, accumulate);
     return check_launch();
+}
+
+extern "C" int pa_gather_rows(const void* in, const int32_t* idx, int n_idx, int64_t row_bytes, void* out, void* stream) {
+    if (!in || !idx || !out || n_idx <= 0 || row_bytes <= 0 || (row_bytes & 3)) return PA_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_idx), dim3(row_bytes >= 2048 ? 128 : 64), 0, (hipStream_t)stream,
+                       (const char*)in, idx, row_bytes, (char*)out, 0);
+    return check_launch();
+}
+
+extern "C" int pa_scatter_rows(const void* in, const int32_t* idx, int n_idx, int64_t row_bytes, void* out, void* stream) {
+    if (!in || !idx || !out || n_idx <= 0 || row_bytes <= 0 || (row_bytes & 3)) return PA_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_idx), dim3(row_bytes >= 2048 ? 128 : 64), 0, (hipStream_t)stream,
+                       (const char*)in, idx, row_bytes, (char*)out, 1);
+    return check_launch();
+}
+
+extern "C" int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, int64_t rows, void* stream) {
+    if (!ptr || pitch_bytes < width_bytes || width_bytes <= 0 || rows <= 0) return PA_EINVAL;
+    hipError_t e = pitch_bytes == width_bytes
+                       ? hipMemsetAsync(ptr, 0, (size_t)(width_bytes * rows), (hipStream_t)stream)
+                       : hipMemset2DAsync(ptr, (size_t)pitch_bytes, 0, (size_t)width_bytes, (size_t)rows, (hipStream_t)stream);
+    return e == hipSuccess ? PA_OK : set_hip_error(e);
 }

@@ -250,24 +250,51 @@ def colsum_f32(x, out_f32, accumulate=False):
 
 
 # ---- attention -------------------------------------------------------------------------------
-def attention_fwd(qkv, B, H, N, scale):
+def attention_fwd(qkv, B, H, N, scale, nq=None):
+    """o[(b*nq+q)][H*64], lse[(b*H+h)*nq+q] for the first nq queries of every sequence (nq=None: all N)."""
     dtype = PA_DTYPE[qkv.dtype]
+    nq = N if nq is None else nq
     D = H * 64
-    o = torch.empty((B * N, D), device=qkv.device, dtype=qkv.dtype)
-    lse = torch.empty((B * H * N,), device=qkv.device, dtype=torch.float32)
-    check(_lib.load().pa_attention_fwd(_p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, scale, dtype,
+    o = torch.empty((B * nq, D), device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty((B * H * nq,), device=qkv.device, dtype=torch.float32)
+    check(_lib.load().pa_attention_fwd(_p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, nq, scale, dtype,
                                        _stream()), "pa_attention_fwd")
     return o, lse
 
 
-def attention_bwd(qkv, o, d_o, lse, B, H, N, scale):
+def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None):
+    """dqkv [B*N][3D]; with nq < N (o, d_o, lse compact) the Q third is zero outside the first nq rows."""
     dtype = PA_DTYPE[qkv.dtype]
+    nq = N if nq is None else nq
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    check(_lib.load().pa_attention_bwd(_p(qkv), qkv.stride(0), _p(o), _p(d_o), o.stride(0), _p(lse), _p(delta),
-                                       _p(dqkv), dqkv.stride(0), B, H, N, scale, dtype, _stream()),
+    lib = _lib.load()
+    if nq < N:
+        es = qkv.element_size()
+        check(lib.pa_zero2d(_p(dqkv), dqkv.stride(0) * es, H * 64 * es, B * N, _stream()), "pa_zero2d")
+    check(lib.pa_attention_bwd(_p(qkv), qkv.stride(0), _p(o), _p(d_o), o.stride(0), _p(lse), _p(delta),
+                               _p(dqkv), dqkv.stride(0), B, H, N, nq, scale, dtype, _stream()),
           "pa_attention_bwd")
     return dqkv
+
+
+def gather_rows(x, idx_i32):
+    """out[i] = x[idx[i]] for a 2-D (or 1-D) contiguous tensor."""
+    n = idx_i32.numel()
+    out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    row_bytes = x.stride(0) * x.element_size()
+    check(_lib.load().pa_gather_rows(_p(x), _p(idx_i32), n, row_bytes, _p(out), _stream()), "pa_gather_rows")
+    return out
+
+
+def scatter_rows_into_zeros(x_rows, idx_i32, n_rows):
+    """zeros(n_rows, D) with out[idx[i]] = x_rows[i]"""
+    out = torch.empty((n_rows,) + tuple(x_rows.shape[1:]), device=x_rows.device, dtype=x_rows.dtype)
+    row_bytes = x_rows.stride(0) * x_rows.element_size()
+    lib = _lib.load()
+    check(lib.pa_zero2d(_p(out), row_bytes, row_bytes, n_rows, _stream()), "pa_zero2d")
+    check(lib.pa_scatter_rows(_p(x_rows), _p(idx_i32), idx_i32.numel(), row_bytes, _p(out), _stream()), "pa_scatter_rows")
+    return out
 
 
 # ---- patch embedding -------------------------------------------------------------------------

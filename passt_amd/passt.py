@@ -170,6 +170,16 @@ class _Staged:
         return out
 
 
+def _prefix_rows(model, B, Ntok, device):
+    """int32 row indices of the cls / dist tokens in the [B*Ntok] token matrix (cached per shape)."""
+    key = ("pidx", B, Ntok, str(device))
+    t = model._scratch.get(key)
+    if t is None:
+        idx = (np.arange(B, dtype=np.int32)[:, None] * Ntok + np.arange(2, dtype=np.int32)[None, :]).reshape(-1)
+        t = model._scratch[key] = torch.from_numpy(idx).to(device)
+    return t
+
+
 def _precision(model):
     if model.precision is not None:
         return {"fp32": PA_F32, "f32": PA_F32, "bf16": PA_BF16}[model.precision]
@@ -212,18 +222,30 @@ def passt_forward(model, x, save):
 
     xs = tok.view(M, D)
     saved = []
-    for blk in model.blocks:
+    nblk = len(model.blocks)
+    for bi, blk in enumerate(model.blocks):
+        last = bi == nblk - 1
         ln1, mean1, rstd1 = ops.layernorm_fwd(xs, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save)
         qkv = ops.linear(ln1, st.get(blk.attn.qkv.weight, dt, False), blk.attn.qkv.bias, dt)
-        att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale)
-        x_mid = ops.linear_resid(att, st.get(blk.attn.proj.weight, dt, False), blk.attn.proj.bias, xs, dt)
+        if not last:
+            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale)
+            x_res = xs
+        else:
+            # PREFIX-ONLY TAIL.  The network output reads the last block at the cls/dist rows only
+            # (models/passt.py:570-574, 583), so from here on just those 2 rows per clip are computed: attention for
+            # 2 queries (keys/values still span every token), then proj / LN2 / MLP on [2B, D].  Exact, not an
+            # approximation: the reference computes the other N-2 rows and discards them.
+            pidx = _prefix_rows(model, B, Ntok, x.device)
+            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale, nq=2)
+            x_res = ops.gather_rows(xs, pidx)
+        x_mid = ops.linear_resid(att, st.get(blk.attn.proj.weight, dt, False), blk.attn.proj.bias, x_res, dt)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save)
         h_pre, h_act = ops.linear_gelu(ln2, st.get(blk.mlp.fc1.weight, dt, False), blk.mlp.fc1.bias, dt)
         x_out = ops.linear_resid(h_act, st.get(blk.mlp.fc2.weight, dt, False), blk.mlp.fc2.bias, x_mid, dt)
         if save:
             saved.append((xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act))
         xs = x_out
-    xl = xs.view(B, Ntok, D)
+    xl = xs.view(B, 2, D)                  # compact: the two prefix tokens of every clip
     feat, hn, stats = ops.head_pre_fwd(xl, model.norm.weight, model.norm.bias, model.norm.eps, model.head[0].weight,
                                        model.head[0].bias, model.head[0].eps)
     logits = ops.linear_f32_fwd(hn, model.head[1].weight, model.head[1].bias)
@@ -300,13 +322,15 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         ops.colsum_f32(part4[:, j, :], g[name])
     if on_block_done:
         on_block_done(len(model.blocks))
-    dx = dxl.view(M, D)
+    nblk = len(model.blocks)
+    dx = dxl.view(2 * B, D)                 # gradient w.r.t. the compact (prefix-rows) output of the last block
     dx_lp = ops.convert(dx, dt)
-    for i in range(len(model.blocks) - 1, -1, -1):
+    for i in range(nblk - 1, -1, -1):
         blk = model.blocks[i]
+        last = i == nblk - 1
         pfx = f"blocks.{i}."
         xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = ctx["saved"][i]
-        # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+        # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))      (on [2B, D] rows for the last block)
         wgrad_async(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"])
         d_pre = torch.empty_like(h_pre)
         ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre)
@@ -320,10 +344,16 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         wgrad_async(dx_lp, att, g[pfx + "attn.proj.weight"], g[pfx + "attn.proj.bias"])
         d_att = torch.empty_like(att)
         ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
-        d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"])
+        if not last:
+            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"])
+            dres = dx
+        else:
+            # only 2 queries per sequence carry a gradient; the residual gradient lives on the prefix rows only
+            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"], nq=2)
+            dres = ops.scatter_rows_into_zeros(dx, _prefix_rows(model, B, Ntok, dx.device), M)
         d_ln1 = torch.empty_like(ln1)
         ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)
-        dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dx, g[pfx + "norm1.weight"],
+        dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dres, g[pfx + "norm1.weight"],
                                       g[pfx + "norm1.bias"], i > 0)
         # last weight gradient of the block; the side stream (ordered after the LayerNorm gradients above)
         # then reports the block complete, so its all-reduce bucket starts without stalling the main stream

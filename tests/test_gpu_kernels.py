@@ -362,3 +362,41 @@ def test_ce_mixup_loss():
     ref2.backward()
     loss2, dz2 = ops.ce_mixup_fwd_bwd(z.to(DEV), y.to(torch.int32).to(DEV))
     assert abs(float(loss2) - float(ref2.detach())) < 1e-5 and rel_err(dz2, zr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("B,H,N,nq", [(3, 2, 474, 2), (2, 3, 130, 70), (2, 2, 67, 1)])
+def test_attention_prefix_queries(dt, B, H, N, nq):
+    """query-limited attention (the last block only needs the cls/dist rows): compact o/lse, and in the
+    backward K/V gradients from nq queries only + a Q gradient that is zero outside the first nq rows."""
+    D = H * 64
+    qkv = rnd(B * N, 3 * D, seed=70, scale=1.5).to(TD[dt]).to(DEV)
+    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, nq=nq)
+    assert o.shape == (B * nq, D) and lse.shape == (B * H * nq,)
+    d_o = rnd(B * nq, D, seed=71).to(TD[dt]).to(DEV)
+    # reference: full attention, gradient injected only at the first nq queries of every sequence
+    d_full = torch.zeros(B, N, D, dtype=torch.float64)
+    d_full[:, :nq] = d_o.double().cpu().view(B, nq, D)
+    ro, rlse, rdqkv = _attn_ref(qkv, B, H, N, 0.125, d_full.view(B * N, D))
+    ro_c = ro.view(B, N, D)[:, :nq].reshape(B * nq, D)
+    assert rel_err(o, ro_c) < tol(dt, 2e-5, 1.5e-2)
+    assert float((lse.double().cpu().view(B, H, nq) - rlse[:, :, :nq]).abs().max()) < tol(dt, 2e-5, 2e-2)
+    dqkv = ops.attention_bwd(qkv, o, d_o, lse, B, H, N, 0.125, nq=nq)
+    e = rel_err(dqkv, rdqkv)
+    record(f"attention_prefix[{dt},{B},{H},{N},{nq}]", dqkv=e)
+    assert e < tol(dt, 5e-5, 4e-2), e
+    q_part = dqkv.view(B, N, 3 * D)[:, nq:, :D]
+    assert float(q_part.float().abs().max()) == 0.0
+
+
+def test_gather_scatter_rows():
+    x = rnd(50, 96, seed=72).to(DEV)
+    idx = torch.tensor([3, 0, 49, 17], dtype=torch.int32, device=DEV)
+    g = ops.gather_rows(x, idx)
+    assert torch.equal(g.cpu(), x.cpu()[idx.cpu().long()])
+    s = ops.scatter_rows_into_zeros(g, idx, 50)
+    ref = torch.zeros(50, 96)
+    ref[idx.cpu().long()] = g.cpu()
+    assert torch.equal(s.cpu(), ref)
+    xb = rnd(20, 64, seed=73).to(torch.bfloat16).to(DEV)
+    assert torch.equal(ops.gather_rows(xb, idx[:2]).cpu(), xb.cpu()[idx[:2].cpu().long()])
