@@ -94,12 +94,15 @@ int pa_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
                      float* mean, float* rstd, int M, int D, float eps, void* stream);
 /* dx[M][D] = (dres ? dres : 0) + LN'(dy); optional dx_lp (dtype) copy of dx for the next GEMM.
  * dgamma/dbeta[D] are OVERWRITTEN (or accumulated when accumulate != 0).
+ * dcolsum[D] (optional): column sums of the OUTPUT dx -- the bias gradient of the Linear whose output fed
+ * this LayerNorm through the residual stream (proj.bias for norm2, the previous block's fc2.bias for norm1),
+ * fused here because the kernel already reduces over rows.
  * ws: f32 workspace of pa_layernorm_bwd_ws_floats(M, D) elements. */
 int64_t pa_layernorm_bwd_ws_floats(int M, int D);
 int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gamma,
                      const float* mean, const float* rstd, const float* dres, float* dx,
-                     void* dx_lp, float* dgamma, float* dbeta, int accumulate, float* ws, int M,
-                     int D, void* stream);
+                     void* dx_lp, float* dgamma, float* dbeta, float* dcolsum, int accumulate, float* ws,
+                     int M, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[M][N] = A[M][K] * B[N][K]^T  (both operands K-contiguous), MFMA, f32 accumulation.

@@ -41,7 +41,7 @@ SIGNATURES = {
     "pa_transpose": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
-    "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_colsum_ws_floats": (i64, [i32, i32]),

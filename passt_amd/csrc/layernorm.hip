@@ -78,16 +78,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, T* __restrict__ dx_lp,
                                                      float* __restrict__ ws, int M, int D) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][D]
+    // ws[block][3][D]: partial column sums of dy*xhat (dgamma), dy (dbeta) and of the OUTPUT dx (the bias gradient
+    // of the Linear that produced this LayerNorm's input: proj for norm2, the previous block's fc2 for norm1)
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][3][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
-    float4 g[MAXV], ag[MAXV], ab[MAXV];
+    float4 g[MAXV], ag[MAXV], ab[MAXV], ac[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         g[i] = c < nv ? *(const float4*)(gamma + 4 * c) : make_float4(0, 0, 0, 0);
         ag[i] = make_float4(0, 0, 0, 0);
         ab[i] = make_float4(0, 0, 0, 0);
+        ac[i] = make_float4(0, 0, 0, 0);
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], r = rstd[row];
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
                 *(float4*)(dx + base + 4 * c) = o;
                 if (dx_lp) store4<T>(dx_lp + base + 4 * c, o);
+                ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
             }
         }
     }
@@ -130,47 +134,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            *(float4*)(red + (wave * 2 + 0) * D + 4 * c) = ag[i];
-            *(float4*)(red + (wave * 2 + 1) * D + 4 * c) = ab[i];
+            *(float4*)(red + (wave * 3 + 0) * D + 4 * c) = ag[i];
+            *(float4*)(red + (wave * 3 + 1) * D + 4 * c) = ab[i];
+            *(float4*)(red + (wave * 3 + 2) * D + 4 * c) = ac[i];
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * D; k += 256) {
+    for (int k = threadIdx.x; k < 3 * D; k += 256) {
         const int which = k / D, c = k - which * D;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * D + c];
-        ws[(int64_t)blockIdx.x * 2 * D + k] = s;
+        for (int w = 0; w < 4; ++w) s += red[(w * 3 + which) * D + c];
+        ws[(int64_t)blockIdx.x * 3 * D + k] = s;
     }
 }
 
-// out[which][c] (+)= sum_b ws[b][which][c];  block = 16 columns x 16 row groups (many small blocks:
-// the partials are only a few MB, parallelism matters more than coalescing width)
+// out[which][c] (+)= sum_b ws[b][which][c], which = dgamma | dbeta | dcol(optional);  block = 16 columns x 16 row
+// groups (many small blocks: the partials are only a few MB, parallelism matters more than coalescing width)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int accumulate) {
+                                                            float* __restrict__ dcol, int accumulate) {
     __shared__ float red[16][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int k = blockIdx.x * 16 + cx;   // index into [2][D]
+    const int k = blockIdx.x * 16 + cx;   // index into [3][D]
+    const int nk = dcol ? 3 * D : 2 * D;
     float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (k < 2 * D) {
+    if (k < nk) {
         int b = ry;
         for (; b + 48 < nblk; b += 64) {          // 4 loads in flight
-            s += ws[(int64_t)b * 2 * D + k];
-            s1 += ws[(int64_t)(b + 16) * 2 * D + k];
-            s2 += ws[(int64_t)(b + 32) * 2 * D + k];
-            s3 += ws[(int64_t)(b + 48) * 2 * D + k];
+            s += ws[(int64_t)b * 3 * D + k];
+            s1 += ws[(int64_t)(b + 16) * 3 * D + k];
+            s2 += ws[(int64_t)(b + 32) * 3 * D + k];
+            s3 += ws[(int64_t)(b + 48) * 3 * D + k];
         }
-        for (; b < nblk; b += 16) s += ws[(int64_t)b * 2 * D + k];
+        for (; b < nblk; b += 16) s += ws[(int64_t)b * 3 * D + k];
     }
     s = (s + s1) + (s2 + s3);
     red[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && k < 2 * D) {
+    if (ry == 0 && k < nk) {
         s = 0.f;
 #pragma unroll
         for (int y = 0; y < 16; ++y) s += red[y][cx];
-        float* out = k < D ? dgamma + k : dbeta + (k - D);
+        float* out = k < D ? dgamma + k : (k < 2 * D ? dbeta + (k - D) : dcol + (k - 2 * D));
         *out = (accumulate ? *out : 0.f) + s;
     }
 }
@@ -199,16 +205,16 @@ extern "C" int pa_layernorm_fwd(const float* x, const float* gamma, const float*
 
 static int ln_bwd_blocks(int M) { return (int)std::min<int64_t>(LN_BWD_BLOCKS, cdiv(M, 4)); }
 
-extern "C" int64_t pa_layernorm_bwd_ws_floats(int M, int D) { return (int64_t)ln_bwd_blocks(M) * 2 * D; }
+extern "C" int64_t pa_layernorm_bwd_ws_floats(int M, int D) { return (int64_t)ln_bwd_blocks(M) * 3 * D; }
 
 extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
-                                void* dx_lp, float* dgamma, float* dbeta, int accumulate, float* ws,
+                                void* dx_lp, float* dgamma, float* dbeta, float* dcolsum, int accumulate, float* ws,
                                 int M, int D, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || M <= 0 || D <= 0) return PA_EINVAL;
     if (D % 4 || D > LN_MAXV * 256) return PA_EUNSUPPORTED;
     const int nblk = ln_bwd_blocks(M);
-    const size_t lds = (size_t)8 * D * sizeof(float);
+    const size_t lds = (size_t)12 * D * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
     const int nvl = (int)cdiv(D, 256);
@@ -222,6 +228,6 @@ extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const
 #undef PA_LN_BWD
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * D, 16)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(3 * D, 16)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, dcolsum, accumulate);
     return check_launch();
 }

@@ -84,8 +84,8 @@ def layernorm_fwd(x, gamma, beta, eps, dtype, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumulate=False):
-    """Returns (dx f32, dx_lp or None).  dgamma/dbeta are written in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumulate=False, dcolsum=None):
+    """Returns (dx f32, dx_lp or None).  dgamma/dbeta (and dcolsum = column sums of dx, if given) are written in place."""
     M, D = x.shape
     dtype = PA_DTYPE[dy.dtype]
     lib = _lib.load()
@@ -93,7 +93,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
     dx_lp = torch.empty((M, D), device=x.device, dtype=dy.dtype) if (want_lp and dtype != PA_F32) else None
     ws = torch.empty(lib.pa_layernorm_bwd_ws_floats(M, D), device=x.device, dtype=torch.float32)
     check(lib.pa_layernorm_bwd(_p(dy), dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dx_lp),
-                               _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, D, _stream()), "pa_layernorm_bwd")
+                               _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), M, D, _stream()),
+          "pa_layernorm_bwd")
     return dx, (dx if dtype == PA_F32 else dx_lp)
 
 

@@ -331,7 +331,9 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         pfx = f"blocks.{i}."
         xs, ln1, mean1, rstd1, qkv, att, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = ctx["saved"][i]
         # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))      (on [2B, D] rows for the last block)
-        wgrad_async(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"])
+        # fc2.bias gradient = column sums of dx: already produced by the LayerNorm backward that made dx (the next
+        # block's norm1) -- except for the last block, whose dx comes from the head
+        wgrad_async(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"] if last else None)
         d_pre = torch.empty_like(h_pre)
         ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre)
         wgrad_async(d_pre, ln2, g[pfx + "mlp.fc1.weight"], g[pfx + "mlp.fc1.bias"])
@@ -339,9 +341,9 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
         del d_pre
         dx, dx_lp = ops.layernorm_bwd(d_ln2, x_mid, blk.norm2.weight, mean2, rstd2, dx, g[pfx + "norm2.weight"],
-                                      g[pfx + "norm2.bias"], True)
-        # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-        wgrad_async(dx_lp, att, g[pfx + "attn.proj.weight"], g[pfx + "attn.proj.bias"])
+                                      g[pfx + "norm2.bias"], True, dcolsum=g[pfx + "attn.proj.bias"])
+        # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))      (proj.bias gradient came out of LN2' above)
+        wgrad_async(dx_lp, att, g[pfx + "attn.proj.weight"], None)
         d_att = torch.empty_like(att)
         ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
         if not last:
@@ -354,7 +356,8 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         d_ln1 = torch.empty_like(ln1)
         ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)
         dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dres, g[pfx + "norm1.weight"],
-                                      g[pfx + "norm1.bias"], i > 0)
+                                      g[pfx + "norm1.bias"], i > 0,
+                                      dcolsum=g[f"blocks.{i - 1}.mlp.fc2.bias"] if i > 0 else None)
         # last weight gradient of the block; the side stream (ordered after the LayerNorm gradients above)
         # then reports the block complete, so its all-reduce bucket starts without stalling the main stream
         wgrad_async(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], done=i)

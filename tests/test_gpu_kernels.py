@@ -196,7 +196,9 @@ def test_layernorm(dt, M, D):
     ref.backward(dy.double().cpu())
     dg = torch.empty(D, device=DEV)
     db = torch.empty(D, device=DEV)
-    dx, dx_lp = ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dg, db, True)
+    dcol = torch.full((D,), 7.0, device=DEV)
+    dx, dx_lp = ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dg, db, True, dcolsum=dcol)
+    assert rel_err(dcol, (xr.grad + dres.double().cpu()).sum(0)) < 2e-5
     e1 = rel_err(dx, xr.grad + dres.double().cpu())
     e2, e3 = rel_err(dg, gr.grad), rel_err(db, br.grad)
     record(f"layernorm[{dt},{M},{D}]", fwd=e, dx=e1, dgamma=e2, dbeta=e3)
