@@ -22,60 +22,85 @@ static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
 
 
 
-// Shared epilogue: the 2x2 MFMA accumulators of this wave (64x64 outputs at rows m0 + wr*64, columns
-// n0 + wc*64) -> per-wave LDS slab -> 8-wide row vectors with the fused epilogue math.
-// vmcnt counts stores as well as loads on CDNA and retires in order, so a wait for ANY load also waits for
-// every store issued before it: the bias is therefore settled once up front (with the waitcnt builtin, which
-// the compiler's own wait insertion understands), and each 32-row pass issues all of its auxiliary loads
-// first and then all of its stores back to back, with no wait in between.
-template <typename T, int EPI, int TM = 2>
-__device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* smem, int m0,
-                                              int n0, int wave, int wr, int wc, int lane) {
-    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused below
-    float* slab = (float*)smem + wave * (32 * 68);
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    const int ncol = n0 + wc * 64 + ecol;
-    const bool colok = ncol < a.N;               // N % 8 == 0: the lane's 8-vector is all in or all out
-    float bias8[8];
+// Shared epilogue: the TM x 2 MFMA accumulators of this wave (TM*32 x 64 outputs at rows m0 + wr*TM*32,
+// columns n0 + wc*64) -> per-wave LDS slab [32][68] -> 8-wide row vectors with the fused epilogue math.
+//
+// The epilogue of a tile is latency bound, not bandwidth bound (profiles/r01_epilogue_experiment.json: it
+// costs the same with 60 resident workgroups as with 252), and vmcnt counts stores as well as loads and
+// retires in order, so a load issued after a store waits for that store's write acknowledge.  Hence:
+//   * the bias row is requested by the caller BEFORE the K loop (load_bias8) -- its latency is never exposed;
+//   * auxiliary rows (residual / pre-activation) are requested AUX_DEPTH passes ahead as raw 16-byte
+//     vectors (decoded only when used): with AUX_DEPTH == TM every load of the tile is in flight before the
+//     first store is issued;
+//   * each pass issues its stores back to back with no wait in between.
+static constexpr int SLAB_BYTES = 32 * 68 * 4;     // 8704 per wave
+
+template <int EPI, int TM> __host__ __device__ constexpr int aux_depth() {
+    return EPI == PA_EPI_DGELU ? TM : (EPI == PA_EPI_RESID ? (TM <= 3 ? TM : 2) : 0);
+}
+
+template <int EPI>
+__device__ __forceinline__ void load_bias8(const pa_gemm_args& a, int n0, int wc, int lane, float (&bias8)[8]) {
+    const int ncol = n0 + wc * 64 + (lane & 7) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
     if constexpr (EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU) {
-        if (a.bias) {
+        if (a.bias && ncol < a.N) {
+            const f32x4 lo = *(const f32x4*)(a.bias + ncol), hi = *(const f32x4*)(a.bias + ncol + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = colok ? a.bias[ncol + e] : 0.f;
+            for (int e = 0; e < 4; ++e) { bias8[e] = lo[e]; bias8[4 + e] = hi[e]; }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): bias landed; nothing below waits on it again
     }
-    // auxiliary inputs (residual / pre-activation) of pass i+1 are requested before pass i is processed, so
-    // their HBM latency hides under the slab transpose and the stores of the previous pass
-    constexpr bool HAS_AUX = (EPI == PA_EPI_RESID || EPI == PA_EPI_DGELU);
-    float x[2][4][8];
+}
+
+template <typename T, int EPI, int TM = 2>
+__device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[TM][2], float* slab, int m0,
+                                              int n0, int split, int wr, int wc, int lane, const float (&bias8)[8]) {
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int ncol = n0 + wc * 64 + ecol;
+    const bool colok = ncol < a.N;               // N % 8 == 0: the lane's 8-vector is all in or all out
+    constexpr int P = aux_depth<EPI, TM>();
+    constexpr int NV = (EPI == PA_EPI_RESID || sizeof(T) == 4) ? 2 : 1;     // 16-byte vectors per 8 aux elements
+    f32x4 xr[P > 0 ? P : 1][4][NV];
     auto pass_row = [&](int i, int it) {
         const int m = m0 + wr * (TM * 32) + i * 32 + it * 8 + erow;
         return (m < a.M && colok) ? m : -1;
     };
     auto load_aux = [&](int slot, int i) {
-        if constexpr (HAS_AUX) {
+        if constexpr (P > 0) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int m = pass_row(i, it);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[slot][it][e] = 0.f;
+                for (int k = 0; k < NV; ++k) xr[slot][it][k] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m >= 0) {
+                    const char* src;
                     if constexpr (EPI == PA_EPI_RESID) {
                         const int64_t rrow = a.row_mod > 0 ? m % a.row_mod : m;
-                        load8<float>(a.resid + rrow * a.ldr + ncol, x[slot][it]);
+                        src = (const char*)(a.resid + rrow * a.ldr + ncol);
                     } else {
-                        load8<T>((const T*)a.aux + (int64_t)m * a.ldaux + ncol, x[slot][it]);
+                        src = (const char*)((const T*)a.aux + (int64_t)m * a.ldaux + ncol);
                     }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) xr[slot][it][k] = *(const f32x4*)(src + 16 * k);
                 }
             }
         }
     };
-    load_aux(0, 0);
+    auto aux_val = [&](int slot, int it, float (&x)[8]) {
+        if constexpr (NV == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = xr[slot][it][0][e]; x[4 + e] = xr[slot][it][1][e]; }
+        } else {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, xr[slot][it][0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)b[e];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < P && i < TM; ++i) load_aux(i, i);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        if (i + 1 < TM) load_aux((i + 1) & 1, i + 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -90,30 +115,37 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[it][e] = lo[e] + bias8[e]; v[it][4 + e] = hi[e] + bias8[4 + e]; }
         }
+        if constexpr (P > 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float x[8];
+                aux_val(i % P, it, x);
+                if constexpr (EPI == PA_EPI_RESID) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[it][e] += x[e];
+                } else {
+                    mul_gelu_grad8<T>(v[it], x);
+                }
+            }
+            if (i + P < TM) load_aux(i % P, i + P);    // the slot was consumed just above
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int m = pass_row(i, it);
             if (m < 0) continue;
-            if constexpr (EPI == PA_EPI_STORE) {
+            if constexpr (EPI == PA_EPI_STORE || EPI == PA_EPI_DGELU) {
                 store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
             } else if constexpr (EPI == PA_EPI_GELU) {
                 float g[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = gelu_erf(v[it][e]);   // of the f32 value (the reference applies GELU before rounding too)
+                gelu8<T>(v[it], g);                  // of the f32 value (the reference applies GELU before rounding too)
                 store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
                 store8<T>((T*)a.out_lp2 + (int64_t)m * a.ldolp2 + ncol, g);
             } else if constexpr (EPI == PA_EPI_RESID) {
                 int64_t orow = m;
                 if (a.row_mod > 0) orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + m % a.row_mod;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[it][e] += x[i & 1][it][e];
                 store8<float>(a.out_f32 + orow * a.ldo32 + ncol, v[it]);
-            } else if constexpr (EPI == PA_EPI_DGELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[it][e] *= gelu_erf_grad(x[i & 1][it][e]);
-                store8<T>((T*)a.out_lp + (int64_t)m * a.ldolp + ncol, v[it]);
             } else {  // PA_EPI_PARTIAL
-                store8<float>(a.out_f32 + ((int64_t)blockIdx.y * a.M + m) * a.ldo32 + ncol, v[it]);
+                store8<float>(a.out_f32 + ((int64_t)split * a.M + m) * a.ldo32 + ncol, v[it]);
             }
         }
     }
@@ -223,6 +255,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
         if (p < nsteps) stage(p, p);
+    float bias8[8];
+    load_bias8<EPI>(a, n0, wc, lane, bias8);
     int buf = 0;
     for (int t = 0; t < nsteps; ++t) {
         // tile t must have landed; up to min(STAGES-2, nsteps-1-t) younger tiles may stay in flight
@@ -257,7 +291,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
         }
         if (++buf == STAGES) buf = 0;
     }
-    gemm_epilogue<T, EPI, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused by the slabs
+    gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8);
 }
 
 template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
@@ -294,41 +329,67 @@ static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
 // (>= 5 barrier intervals before its first use); every wave drains its own DMA (vmcnt 0) just before the
 // barrier that ends tile t's last interval, so the buffer is complete when either group starts reading it.
 // ------------------------------------------------------------------------------------------------
+// The kernel is PERSISTENT: min(#work items, 256) workgroups (one per CU), each walking work items
+// (output tile x K split) round by round.  The first K-tile of the NEXT item is DMA'd during the last K-tile
+// of the current one, so the K loop runs without a prologue bubble across items, and the epilogue's slabs
+// live in the K-tile buffer that was read last (+ a few KiB past the ring), never in the one already
+// holding the next item's data.
+template <int TM> struct StaggerGeom {
+    static constexpr int TBM = 64 * TM, TBN = 256;
+    static constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 48/56/64 KiB
+    static constexpr int SLABS_IN_STAGE = STAGE_BYTES / SLAB_BYTES;                                 // 5 / 6 / 7
+    static constexpr int BIAS_OFF = 2 * STAGE_BYTES + (8 - SLABS_IN_STAGE) * SLAB_BYTES;    // 256 floats: the tile's bias row
+    static constexpr int LDS = BIAS_OFF + 1024;
+};
+
 template <typename T, int EPI, int TM>
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
-                                                              const int nwg, const int ksteps_per_split) {
+                                                              const int nwg, const int ksteps_per_split, const int total) {
+    using G = StaggerGeom<TM>;
     constexpr int WN = 4;
-    constexpr int TBM = 64 * TM, TBN = 256;          // TM = 2/3/4 -> 128/192/256-row tiles (tile quantisation)
+    constexpr int TBM = G::TBM, TBN = G::TBN;         // TM = 2/3/4 -> 128/192/256-row tiles (tile quantisation)
     constexpr int A_PER = TM;                         // A copies per wave per stage: TBM*128/1024/8
-    constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 64 KiB
+    constexpr int A_BYTES = G::A_BYTES, STAGE_BYTES = G::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;      // wr = group
-    int tm, tn;
-    tile_coords(xcd_swizzle(blockIdx.x, nwg), tiles_m, tiles_n, 4, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * TBN;
     const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
-    const int ks_begin = blockIdx.y * ksteps_per_split;
-    const int nsteps = min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;
+    const int nres = gridDim.x, bid = blockIdx.x;
 
+    // work item of this workgroup in round r (or -1): within a round consecutive logical ids share an XCD
+    auto item_of = [&](int r) {
+        const int left = total - r * nres;
+        const int n = min(left, nres);
+        return bid < n ? r * nres + xcd_swizzle(bid, n) : -1;
+    };
+    // DMA cursor: source pointers of the item whose K-tiles are being fetched
     const char* srcA[A_PER];
     const char* srcB[4];
+    auto point_at = [&](int item, int& m0, int& n0, int& split) {
+        int tm, tn;
+        split = item / nwg;
+        tile_coords(item - split * nwg, tiles_m, tiles_n, 4, tm, tn);
+        m0 = tm * TBM;
+        n0 = tn * TBN;
+        const int ks_begin = split * ksteps_per_split;
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        const int q = (wave * A_PER + i) * 64 + lane;
-        const int row = q >> 3;
-        const int c = (q & 7) ^ swz_f128(row);
-        srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
-    }
+        for (int i = 0; i < A_PER; ++i) {
+            const int q = (wave * A_PER + i) * 64 + lane;
+            const int row = q >> 3;
+            const int c = (q & 7) ^ swz_f128(row);
+            srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = (wave * 4 + i) * 64 + lane;
-        const int row = q >> 3;
-        const int c = (q & 7) ^ swz_f128(row);
-        srcB[i] = (const char*)a.B + ((int64_t)min(n0 + row, a.N - 1) * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int q = (wave * 4 + i) * 64 + lane;
+            const int row = q >> 3;
+            const int c = (q & 7) ^ swz_f128(row);
+            srcB[i] = (const char*)a.B + ((int64_t)min(n0 + row, a.N - 1) * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        }
+        return min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;     // K-tiles of the item (>= 1, see launch)
+    };
     auto dmaA = [&](int buf, int step) {
         char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
 #pragma unroll
@@ -344,75 +405,123 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                                              (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[TM][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int rsw = swz_f128(lane);
     const int offA = (wr * (TM * 32) + (lane & 31)) * 128;
     const int offB = (wc * 64 + (lane & 31)) * 128;
     const int half = lane >> 5;
 
-    if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
+    int round = 0;
+    int m0, n0, split;
+    int nsteps = point_at(item_of(0), m0, n0, split);      // grid <= total: every workgroup owns an item in round 0
+    dmaA(0, 0);
+    dmaB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // tile 0 complete for everyone
-    if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+    __builtin_amdgcn_s_barrier();                          // K-tile 0 complete for everyone
+    int gbuf = 0;                                          // ring slot of the K-tile about to be consumed
 
-    for (int t = 0; t < nsteps; ++t) {
-        const char* sA = smem + (t & 1) * STAGE_BYTES;
-        const char* sB = sA + A_BYTES;
-        const bool more = t + 1 < nsteps;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ---------------- L segment ----------------
-            typename Frag<T>::type fa[TM], fb[2];
-            const int coff = ((ph * 2 + half) ^ rsw) << 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
-            if (more) {
-                if (ph == 0) dmaA((t + 1) & 1, t + 1);
-                if (ph == 1) dmaB((t + 1) & 1, t + 1);
-            }
-            if (ph == 3 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---------------- M segment ----------------
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
-            __builtin_amdgcn_s_setprio(0);
-            if (ph == 3 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+    for (;;) {
+        const int next_item = item_of(round + 1);
+        // the tile's bias row goes to LDS (4 bytes per lane, one DMA by each wave of group 0): it is read back in
+        // the epilogue, so it costs no registers during the K loop and its latency is never exposed
+        constexpr bool HAS_BIAS = EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU;
+        if constexpr (HAS_BIAS) {
+            if (a.bias && wr == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + min(n0 + wc * 64 + lane, a.N - 1)),
+                                                 (__attribute__((address_space(3))) void*)(smem + G::BIAS_OFF + wc * 256), 4, 0, 0);
         }
+        f32x16 acc[TM][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
+        if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
+
+        for (int t = 0; t < nsteps; ++t) {
+            const char* sA = smem + gbuf * STAGE_BYTES;
+            const char* sB = sA + A_BYTES;
+            const bool last = t + 1 == nsteps;
+            const bool more = !last || next_item >= 0;
+            // the K-tile fetched during this one: t+1 of this item, or tile 0 of the next item
+            if (last && next_item >= 0) point_at(next_item, m0, n0, split);
+            const int dstep = last ? 0 : t + 1;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                // ---------------- L segment ----------------
+                typename Frag<T>::type fa[TM], fb[2];
+                const int coff = ((ph * 2 + half) ^ rsw) << 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
+                if (more) {
+                    if (ph == 0) dmaA(gbuf ^ 1, dstep);
+                    if (ph == 1) dmaB(gbuf ^ 1, dstep);
+                }
+                if (ph == 3 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- M segment ----------------
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (ph == 3 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            gbuf ^= 1;
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align the two groups: every fragment read is done
+        // slabs go into the ring slot that was read last (gbuf now names the one holding the next item's tile 0)
+        float* slab = (float*)(wave < G::SLABS_IN_STAGE ? smem + (gbuf ^ 1) * STAGE_BYTES + wave * SLAB_BYTES
+                                                        : smem + 2 * STAGE_BYTES + (wave - G::SLABS_IN_STAGE) * SLAB_BYTES);
+        float bias8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if constexpr (HAS_BIAS) {
+            if (a.bias) {
+                const float* brow = (const float*)(smem + G::BIAS_OFF) + wc * 64 + (lane & 7) * 8;
+                const f32x4 lo = *(const f32x4*)brow, hi = *(const f32x4*)(brow + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bias8[e] = lo[e]; bias8[4 + e] = hi[e]; }
+            }
+        }
+        gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8);
+        if (next_item < 0) break;
+        // (re)derive the DMA cursor of the item just started: cheaper than carrying 16 pointer registers
+        // through the epilogue above
+        nsteps = point_at(next_item, m0, n0, split);
+        ++round;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // slabs are dead: the slot may be refilled by the DMA
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();             // re-align the two groups
-    gemm_epilogue<T, EPI, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
 }
 
 template <typename T, int EPI, int TM>
 static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
-    constexpr int LDS = 2 * (64 * TM + 256) * KB;   // 96 / 112 / 128 KiB
-    static_assert(LDS >= 8 * 32 * 68 * 4, "epilogue slabs must fit");
+    using G = StaggerGeom<TM>;
+    static_assert(G::LDS <= 160 * 1024, "LDS budget");
     const int tiles_m = (int)cdiv(a.M, 64 * TM), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
+    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps)      // an empty K split: the generic kernel handles it
+        return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+    const int total = nwg * splits;
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(nwg, splits), dim3(512), LDS, st, a, tiles_m, tiles_n, nwg, per);
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(std::min(total, 256)), dim3(512), G::LDS, st, a, tiles_m,
+                       tiles_n, nwg, per, total);
     return check_launch();
 }
 
@@ -601,7 +710,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const pa_gemm_args a, cons
                 for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
         }
     }
-    gemm_epilogue<T, PA_EPI_PARTIAL, 2>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+    __syncthreads();
+    const float nobias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    gemm_epilogue<T, PA_EPI_PARTIAL, 2>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, nobias);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -745,7 +856,9 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    gemm_epilogue<bf16, PA_EPI_PARTIAL, TM>(a, acc, smem, m0, n0, wave, wr, wc, lane);
+    __syncthreads();
+    const float nobias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    gemm_epilogue<bf16, PA_EPI_PARTIAL, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, nobias);
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {

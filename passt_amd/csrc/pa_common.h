@@ -9,6 +9,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -70,6 +71,68 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float q = gelu_q(fabsf(x), ex);
     const float cdf = x >= 0.0f ? 1.0f - q : q;
     return fmaf(x * 0.39894228040143267794f, ex, cdf);
+}
+
+// ---- GELU for the bf16 epilogues: odd minimax polynomials on the clamped argument, two elements per
+// v_pk_fma_f32 and no transcendental (quarter-rate) instruction.  The fc1 / dgrad-fc2 GEMM epilogues are VALU
+// bound (65536 outputs per CU per tile), so this is ~2.7x cheaper than the erf form above.  Coefficients and
+// error bounds from tools_gelu_fit.py: |Phi err| <= 1.3e-5, |gelu' err| <= 1.5e-4 in f32 evaluation -- 1/30 and
+// 1/10 of a bf16 half-ulp of the stored results.  The f32 parity path keeps gelu_erf / gelu_erf_grad.
+//   Phi(x)   = 1/2 + xc P(xc^2),   gelu'(x) = 1/2 + xc Q(xc^2),   xc = clamp(x, -4.25, 4.25)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 gelu_clamp2(f32x2 x) {
+    return f32x2{__builtin_amdgcn_fmed3f(x[0], -4.25f, 4.25f), __builtin_amdgcn_fmed3f(x[1], -4.25f, 4.25f)};
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x), t = xc * xc;
+    f32x2 p = pk_fma(pk_splat(5.564853169e-11f), t, pk_splat(-5.327756179e-09f));
+    p = pk_fma(p, t, pk_splat(2.255428225e-07f));
+    p = pk_fma(p, t, pk_splat(-5.626429780e-06f));
+    p = pk_fma(p, t, pk_splat(9.341873147e-05f));
+    p = pk_fma(p, t, pk_splat(-1.108561126e-03f));
+    p = pk_fma(p, t, pk_splat(9.815971666e-03f));
+    p = pk_fma(p, t, pk_splat(-6.634449192e-02f));
+    p = pk_fma(p, t, pk_splat(3.989023391e-01f));
+    return x * pk_fma(xc, p, pk_splat(0.5f));
+}
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x), t = xc * xc;
+    f32x2 q = pk_fma(pk_splat(-3.426787246e-11f), t, pk_splat(3.552477616e-09f));
+    q = pk_fma(q, t, pk_splat(-1.634916764e-07f));
+    q = pk_fma(q, t, pk_splat(4.432675237e-06f));
+    q = pk_fma(q, t, pk_splat(-7.936289004e-05f));
+    q = pk_fma(q, t, pk_splat(9.965486026e-04f));
+    q = pk_fma(q, t, pk_splat(-9.040460278e-03f));
+    q = pk_fma(q, t, pk_splat(5.909254817e-02f));
+    q = pk_fma(q, t, pk_splat(-2.653926090e-01f));
+    q = pk_fma(q, t, pk_splat(7.977564352e-01f));
+    return pk_fma(xc, q, pk_splat(0.5f));
+}
+// 8-element forms used by the epilogues: T selects the exact (f32 parity) or the fast (bf16) evaluation
+template <typename T> __device__ __forceinline__ void gelu8(const float (&x)[8], float (&g)[8]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = gelu_erf(x[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 r = gelu_fast2(f32x2{x[e], x[e + 1]});
+            g[e] = r[0]; g[e + 1] = r[1];
+        }
+    }
+}
+template <typename T> __device__ __forceinline__ void mul_gelu_grad8(float (&v)[8], const float (&x)[8]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(x[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 r = f32x2{v[e], v[e + 1]} * gelu_grad_fast2(f32x2{x[e], x[e + 1]});
+            v[e] = r[0]; v[e + 1] = r[1];
+        }
+    }
 }
 
 // ---- 8 consecutive elements <-> 8 floats (16-byte vectors; N % 8 == 0 is an API precondition)
