@@ -8,6 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpasst_amd.so")
+# A/B benchmarking of two builds of the library: PASST_AMD_LIB=/path/to/other.so (same ABI)
+LIB_PATH = os.environ.get("PASST_AMD_LIB", LIB_PATH)
 
 PA_F32, PA_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_PARTIAL = 0, 1, 2, 3, 4

@@ -339,7 +339,9 @@ template <int TM> struct StaggerGeom {
     static constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 48/56/64 KiB
     static constexpr int SLABS_IN_STAGE = STAGE_BYTES / SLAB_BYTES;                                 // 5 / 6 / 7
     static constexpr int BIAS_OFF = 2 * STAGE_BYTES + (8 - SLABS_IN_STAGE) * SLAB_BYTES;    // 256 floats: the tile's bias row
-    static constexpr int LDS = BIAS_OFF + 1024;
+    static constexpr int TAB_OFF = BIAS_OFF + 1024;         // {m0, n0, split, -} of this workgroup's item in every round
+    static constexpr int MAX_ROUNDS = 512;
+    static constexpr int LDS = TAB_OFF + MAX_ROUNDS * 16;
 };
 
 template <typename T, int EPI, int TM>
@@ -358,50 +360,66 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
     const int nres = gridDim.x, bid = blockIdx.x;
 
-    // work item of this workgroup in round r (or -1): within a round consecutive logical ids share an XCD
-    auto item_of = [&](int r) {
-        const int left = total - r * nres;
-        const int n = min(left, nres);
-        return bid < n ? r * nres + xcd_swizzle(bid, n) : -1;
-    };
-    // DMA cursor: source pointers of the item whose K-tiles are being fetched
-    const char* srcA[A_PER];
-    const char* srcB[4];
-    auto point_at = [&](int item, int& m0, int& n0, int& split) {
+    // Work items of this workgroup: round r -> logical id r*nres + xcd_swizzle(bid, n_r) (within a round
+    // consecutive ids share an XCD and walk an L2-friendly patch of tiles).  The id -> (tile, split) mapping
+    // needs integer divisions, which have no scalar instruction: one lane per round does them once, up
+    // front, into an LDS table; the K loop only reads the table.
+    const int full_rounds = total / nres;
+    const int my_rounds = full_rounds + (bid < total - full_rounds * nres ? 1 : 0);
+    int4* tab = (int4*)(smem + G::TAB_OFF);
+    for (int r = tid; r < my_rounds; r += 512) {
+        const int n = min(total - r * nres, nres);
+        const int item = r * nres + xcd_swizzle(bid, n);
         int tm, tn;
-        split = item / nwg;
-        tile_coords(item - split * nwg, tiles_m, tiles_n, 4, tm, tn);
-        m0 = tm * TBM;
-        n0 = tn * TBN;
+        const int sp = item / nwg;
+        tile_coords(item - sp * nwg, tiles_m, tiles_n, 4, tm, tn);
+        tab[r] = make_int4(tm * TBM, tn * TBN, sp, 0);
+    }
+    __syncthreads();
+    // DMA cursor of the item whose K-tiles are being fetched: a uniform 64-bit base per operand (SGPRs: tile
+    // origin + K offset) plus per-lane 32-bit offsets (row within the tile, clamped at the matrix edge, and the
+    // swizzled 16-byte chunk) -- a handful of VALU per tile and none per K-tile.
+    const char* baseA;
+    const char* baseB;
+    uint32_t voffA[A_PER], voffB[4];
+    auto point_at = [&](int r, int& m0, int& n0, int& split) {
+        const int4 e = tab[r];
+        m0 = __builtin_amdgcn_readfirstlane(e.x);
+        n0 = __builtin_amdgcn_readfirstlane(e.y);
+        split = __builtin_amdgcn_readfirstlane(e.z);
         const int ks_begin = split * ksteps_per_split;
+        baseA = (const char*)a.A + (int64_t)m0 * a.lda * sizeof(T) + (int64_t)ks_begin * KB;
+        baseB = (const char*)a.B + (int64_t)n0 * a.ldb * sizeof(T) + (int64_t)ks_begin * KB;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int q = (wave * A_PER + i) * 64 + lane;
             const int row = q >> 3;
             const int c = (q & 7) ^ swz_f128(row);
-            srcA[i] = (const char*)a.A + ((int64_t)min(m0 + row, a.M - 1) * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+            voffA[i] = (uint32_t)min(row, a.M - 1 - m0) * (uint32_t)(a.lda * (int)sizeof(T)) + c * 16;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = (wave * 4 + i) * 64 + lane;
             const int row = q >> 3;
             const int c = (q & 7) ^ swz_f128(row);
-            srcB[i] = (const char*)a.B + ((int64_t)min(n0 + row, a.N - 1) * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+            voffB[i] = (uint32_t)min(row, a.N - 1 - n0) * (uint32_t)(a.ldb * (int)sizeof(T)) + c * 16;
         }
         return min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;     // K-tiles of the item (>= 1, see launch)
     };
     auto dmaA = [&](int buf, int step) {
         char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
+        const char* sb = baseA + (int64_t)step * KB;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffA[i]),
                                              (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
     };
     auto dmaB = [&](int buf, int step) {
         char* sB = smem + buf * STAGE_BYTES + A_BYTES + wave * 4096;
+        const char* sb = baseB + (int64_t)step * KB;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KB),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffB[i]),
                                              (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
     };
 
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
 
     int round = 0;
     int m0, n0, split;
-    int nsteps = point_at(item_of(0), m0, n0, split);      // grid <= total: every workgroup owns an item in round 0
+    int nsteps = point_at(0, m0, n0, split);               // grid <= total: every workgroup owns an item in round 0
     dmaA(0, 0);
     dmaB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     int gbuf = 0;                                          // ring slot of the K-tile about to be consumed
 
     for (;;) {
-        const int next_item = item_of(round + 1);
+        const bool have_next = round + 1 < my_rounds;
         // the tile's bias row goes to LDS (4 bytes per lane, one DMA by each wave of group 0): it is read back in
         // the epilogue, so it costs no registers during the K loop and its latency is never exposed
         constexpr bool HAS_BIAS = EPI != PA_EPI_PARTIAL && EPI != PA_EPI_DGELU;
@@ -443,9 +461,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             const char* sA = smem + gbuf * STAGE_BYTES;
             const char* sB = sA + A_BYTES;
             const bool last = t + 1 == nsteps;
-            const bool more = !last || next_item >= 0;
+            const bool more = !last || have_next;
             // the K-tile fetched during this one: t+1 of this item, or tile 0 of the next item
-            if (last && next_item >= 0) point_at(next_item, m0, n0, split);
+            if (last && have_next) point_at(round + 1, m0, n0, split);
             const int dstep = last ? 0 : t + 1;
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
@@ -493,11 +511,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             }
         }
         gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8);
-        if (next_item < 0) break;
-        // (re)derive the DMA cursor of the item just started: cheaper than carrying 16 pointer registers
-        // through the epilogue above
-        nsteps = point_at(next_item, m0, n0, split);
+        if (!have_next) break;
+        // (re)derive the DMA cursor of the item just started: cheaper than carrying it through the epilogue
         ++round;
+        nsteps = point_at(round, m0, n0, split);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // slabs are dead: the slot may be refilled by the DMA
     }
@@ -512,9 +529,10 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
-    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps)      // an empty K split: the generic kernel handles it
-        return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
     const int total = nwg * splits;
+    // an empty K split, or more rounds than the item table holds: the generic kernel handles it
+    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps || cdiv(total, 256) > G::MAX_ROUNDS)
+        return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
@@ -753,9 +771,10 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
     const int st_begin = blockIdx.y * steps_per_split;
     const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
 
-    // this wave's 4 + 4 LDS-DMA pieces per stage: piece q = wave*4+i covers tile rows 2q, 2q+1 (512 B each)
-    const char* srcA[4];
-    const char* srcB[4];
+    // this wave's 4 + 4 LDS-DMA pieces per stage: piece q = wave*4+i covers tile rows 2q, 2q+1 (512 B each).
+    // Source address = uniform base of the stage (SGPRs, advanced by 64 token rows per stage) + a per-lane
+    // 32-bit offset fixed for the whole kernel: no 64-bit vector arithmetic in the K loop.
+    uint32_t voffA[4], voffB[4];
     int rowin[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -764,27 +783,30 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
         const int pc = lane & 31;
         const int c = pc ^ ((row & 3) << 2);
         rowin[i] = row;
-        srcA[i] = (const char*)a.A + (int64_t)min(m0 + c * 8, a.M - 8) * 2;
-        srcB[i] = (const char*)a.B + (int64_t)min(n0 + c * 8, a.N - 8) * 2;
+        voffA[i] = (uint32_t)row * (uint32_t)a.lda * 2u + (uint32_t)min(m0 + c * 8, a.M - 8) * 2u;
+        voffB[i] = (uint32_t)row * (uint32_t)a.ldb * 2u + (uint32_t)min(n0 + c * 8, a.N - 8) * 2u;
     }
-    auto dmaA = [&](int buf, int step) {
-        char* sA = smem + buf * STAGE_BYTES + wave * 4096;
+    const char* baseA = (const char*)a.A + (int64_t)st_begin * MROWS * a.lda * 2;
+    const char* baseB = (const char*)a.B + (int64_t)st_begin * MROWS * a.ldb * 2;
+    auto dma = [&](const char* base, int ld, const uint32_t (&voff)[4], char* dst, int step) {
+        const char* sb = base + (int64_t)step * MROWS * ld * 2;              // uniform
+        const int valid = Mtok - (st_begin + step) * MROWS;                  // token rows that exist in this stage
+        if (valid >= MROWS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t tok = min((int64_t)(st_begin + step) * MROWS + rowin[i], (int64_t)Mtok - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + tok * a.lda * 2),
-                                             (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        } else {   // last stage of the last split: rows past the end re-read the last token (zeroed by zero_tail)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t back = (uint32_t)max(rowin[i] - (valid - 1), 0) * (uint32_t)ld * 2u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (voff[i] - back)),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
         }
     };
-    auto dmaB = [&](int buf, int step) {
-        char* sB = smem + buf * STAGE_BYTES + OP_BYTES + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t tok = min((int64_t)(st_begin + step) * MROWS + rowin[i], (int64_t)Mtok - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + tok * a.ldb * 2),
-                                             (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
-        }
-    };
+    auto dmaA = [&](int buf, int step) { dma(baseA, a.lda, voffA, smem + buf * STAGE_BYTES + wave * 4096, step); };
+    auto dmaB = [&](int buf, int step) { dma(baseB, a.ldb, voffB, smem + buf * STAGE_BYTES + OP_BYTES + wave * 4096, step); };
     // token rows beyond Mtok (last stage only) were filled from a clamped row: zero what THIS wave staged,
     // after its DMA landed and before the barrier that publishes the stage
     auto zero_tail = [&](int buf, int step) {
