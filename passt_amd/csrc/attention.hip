@@ -22,6 +22,10 @@ static constexpr int TROWS = 64;    // streamed rows per LDS tile
 static constexpr float LOG2E = 1.4426950408889634f;
 static constexpr float LN2 = 0.6931471805599453f;
 
+// The softmax / dS element loops are VALU bound (the exponential is a quarter-rate instruction and there is one
+// per score), so everything around it is done two scores per instruction (v_pk_fma_f32 / v_pk_mul_f32).
+__device__ __forceinline__ f32x2 exp2_2(f32x2 a) { return f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
+
 template <typename T> struct Tile {
     static constexpr int RB = HD * (int)sizeof(T);            // row bytes: 128 (bf16) / 256 (f32)
     static constexpr int CPR = RB / 16;                        // 16-byte chunks per row
@@ -118,7 +122,7 @@ static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
 // forward
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 4 : 2))) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
                                                        int ldo, float* __restrict__ lse, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -182,15 +186,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc * sl2);         // running max in log2 units (sl2 > 0)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_new));
-                s[kb][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 p = exp2_2(pk_fma(f32x2{s[kb][r], s[kb][r + 1]}, pk_splat(sl2), pk_splat(-m_new)));
+                s[kb][r] = p[0];
+                s[kb][r + 1] = p[1];
+                ps2 += p;
             }
+        float psum = ps2[0] + ps2[1];
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -217,21 +223,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         if (lane < 32 && q0 + lane < nq) lse[(int64_t)bh * nq + q0 + lane] = m_run * LN2 + __logf(l_run);   // natural log units
         store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, 1.0f / l_run, o + (int64_t)b * nq * ldo + h * HD,
                         ldo, q0, min(32, nq - q0), lane);
-    }
-}
-
-// delta[bh][q] = sum_d dO[q][d] * O[q][d]   (one wave per token row, all heads)
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
-                                                         float* __restrict__ delta, int B, int H, int N) {   // N = rows per sequence of o/d_o (nq)
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= (int64_t)B * N) return;
-    const int b = (int)(m / N), n = (int)(m % N);
-    for (int h = 0; h < H; ++h) {
-        const float v = to_f32<T>(o[m * ldo + h * HD + lane]) * to_f32<T>(d_o[m * ldo + h * HD + lane]);
-        const float s = wave_sum(v);
-        if (lane == 0) delta[((int64_t)b * H + h) * N + n] = s;
     }
 }
 
@@ -298,11 +289,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
                 mma32<T>(dpa, row_frag<T>(sDO, qb * 32 + (lane & 31), st, lane), vf[st]);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {                   // rows r, r+1 of the accumulator are consecutive queries
                 const int ql = qb * 32 + acc_row(r, lane);
-                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -sLse[ql] * LOG2E));
-                sa[r] = p;                                   // P
-                dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;  // dS
+                const f32x2 l2 = f32x2{sLse[ql], sLse[ql + 1]} * pk_splat(-LOG2E);
+                const f32x2 p = exp2_2(pk_fma(f32x2{sa[r], sa[r + 1]}, pk_splat(sl2), l2));
+                const f32x2 ds = p * (f32x2{dpa[r], dpa[r + 1]} - f32x2{sDelta[ql], sDelta[ql + 1]}) * pk_splat(scale);
+                sa[r] = p[0]; sa[r + 1] = p[1];               // P
+                dpa[r] = ds[0]; dpa[r + 1] = ds[1];           // dS
             }
             // queries beyond nq exist only in the last tile (uniform branch); lanes whose own key is beyond
             // N only produce their own, never stored, outputs and need no mask
@@ -337,8 +330,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
-                                                          const T* __restrict__ d_o, int ldo,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
+                                                          const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -359,7 +352,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         dof[s] = *(const typename Frag<T>::type*)(dobase + (int64_t)qrow * ldo + off);
     }
     const float lse2 = lse[(int64_t)bh * nq + qrow] * LOG2E;
-    const float dlt = delta[(int64_t)bh * nq + qrow];
+    // delta[q] = sum_d dO[q][d] O[q][d]: this lane holds half of row q of dO as fragments already; the same
+    // chunks of O are read once here, and the row sum is published for the dK/dV kernel (launched after)
+    float dlt = 0.f;
+    {
+        const T* obase = o + (int64_t)b * nq * ldo + h * HD;
+#pragma unroll
+        for (int s = 0; s < Tile<T>::NFRAG; ++s) {
+            const typename Frag<T>::type of =
+                *(const typename Frag<T>::type*)(obase + (int64_t)qrow * ldo + (s * 2 + (lane >> 5)) * Tile<T>::EPC);
+#pragma unroll
+            for (int e = 0; e < Tile<T>::EPC; ++e) dlt = fmaf((float)dof[s][e], (float)of[e], dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (lane < 32 && q < nq) delta[(int64_t)bh * nq + q] = dlt;
+    }
     f32x16 dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -392,9 +399,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                 mma32<T>(dpa, row_frag<T>(sV, kb * 32 + (lane & 31), st, lane), dof[st]);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -lse2));
-                dpa[r] = p * (dpa[r] - dlt) * scale;   // dS^T
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 p = exp2_2(pk_fma(f32x2{sa[r], sa[r + 1]}, pk_splat(sl2), pk_splat(-lse2)));
+                const f32x2 ds = p * pk_fma(f32x2{dpa[r], dpa[r + 1]}, pk_splat(scale), pk_splat(-dlt * scale));   // dS^T
+                dpa[r] = ds[0]; dpa[r + 1] = ds[1];
             }
             if (kt == ntiles - 1 && (N & (TROWS - 1))) {       // keys beyond N: last tile only
 #pragma unroll
@@ -431,17 +439,14 @@ static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* 
 template <typename T>
 static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo, const float* lse,
                            float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((unsigned)cdiv((int64_t)B * nq, 4)), dim3(256), 0, st,
-                       (const T*)o, (const T*)d_o, ldo, delta, B, H, nq);
+    // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+    dim3 gridq((unsigned)cdiv(nq, 128), (unsigned)(B * H));
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, gridq, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (const T*)o,
+                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
     int rc = check_launch();
     if (rc) return rc;
     dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
-                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
-    rc = check_launch();
-    if (rc) return rc;
-    dim3 gridq((unsigned)cdiv(nq, 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, gridq, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
                        (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
     return check_launch();
 }
