@@ -80,6 +80,20 @@ int pa_mel_frontend_fwd(const float* wave, int B, int L, const float* window, co
  * ------------------------------------------------------------------------------------------ */
 /* out[i] = (dtype) in[i] */
 int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, void* stream);
+/* Batched form of the two calls below, for refreshing every GEMM-ready weight copy after an optimizer
+ * step in ONE launch: entry e reads src[rows][cols] (f32, contiguous) and writes, where non-NULL,
+ * dst[rows][cols] (straight cast) and dst_t[cols][rows] (transposed), both of `dtype` and contiguous.
+ * `descs` is an array of n_desc entries in DEVICE memory; tile_begin is the running count of 64x64 tiles
+ * (ceil(rows/64)*ceil(cols/64) per entry, in order); total_tiles is their sum. */
+typedef struct pa_stage_desc {
+    const float* src;
+    void* dst;
+    void* dst_t;
+    int32_t rows, cols;
+    int32_t tile_begin;
+    int32_t reserved;
+} pa_stage_desc;
+int pa_stage_weights(const pa_stage_desc* descs, int n_desc, int total_tiles, int dtype, void* stream);
 /* in[R][C] (ld = ldi) of dtype in_dtype -> out[C][ldo] of dtype out_dtype, out[c][r] = in[r][c];
  * columns r in [R, ldo) of out are zero-filled (K-padding for the weight-gradient GEMM). */
 int pa_transpose(const void* in, int in_dtype, int R, int C, int ldi, void* out, int out_dtype,

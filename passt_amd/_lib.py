@@ -32,6 +32,10 @@ class GemmArgs(C.Structure):
                 ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32), ("tune", i32)]
 
 
+class StageDesc(C.Structure):          # == pa_stage_desc
+    _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("rows", i32), ("cols", i32), ("tile_begin", i32), ("reserved", i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/passt_amd.h declares
 SIGNATURES = {
     "pa_abi_version": (i32, []),
@@ -41,6 +45,7 @@ SIGNATURES = {
     "pa_mel_frontend_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, C.POINTER(MelParams), vp]),
     "pa_convert_f32": (i32, [vp, vp, i64, i32, vp]),
     "pa_transpose": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "pa_stage_weights": (i32, [vp, i32, i32, i32, vp]),
     "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
     "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),

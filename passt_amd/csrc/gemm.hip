@@ -987,6 +987,73 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
     }
 }
 
+// All weight copies of a step in one launch (pa_stage_weights): block = one 64x64 tile of one entry.
+template <typename TO>
+__global__ __launch_bounds__(256) void stage_weights_kernel(const pa_stage_desc* __restrict__ descs, int n_desc) {
+    __shared__ float tile[64][65];
+    __shared__ int s_entry;
+    const int bid = blockIdx.x;
+    if (threadIdx.x < 64) {        // one wave scans the (short) table: the last entry with tile_begin <= bid
+        int found = -1;
+        for (int e = threadIdx.x; e < n_desc; e += 64)
+            if (descs[e].tile_begin <= bid) found = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, 64));
+        if (threadIdx.x == 0) s_entry = found;
+    }
+    __syncthreads();
+    const pa_stage_desc d = descs[s_entry];
+    const int tiles_c = (d.cols + 63) >> 6;
+    const int t = bid - d.tile_begin;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    TO* dst = (TO*)d.dst;
+    TO* dst_t = (TO*)d.dst_t;
+    if (((d.rows | d.cols) & 3) == 0 && ((uintptr_t)d.src & 15) == 0) {
+        // fast path (every PaSST weight): 16-byte loads, 4-element stores, 128+ contiguous bytes per 16 lanes
+        const int lr = threadIdx.x >> 4, l4 = (threadIdx.x & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + lr + 16 * i, c = c0 + l4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < d.rows && c < d.cols) {
+                v = *(const f32x4*)(d.src + (int64_t)r * d.cols + c);
+                if (dst) {
+                    if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst + (int64_t)r * d.cols + c) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    else *(f32x4*)(dst + (int64_t)r * d.cols + c) = v;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[lr + 16 * i][l4 + k] = v[k];
+        }
+        if (!dst_t) return;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + lr + 16 * i, r = r0 + l4;
+            if (c < d.cols && r < d.rows) {
+                const f32x4 v = {tile[l4][lr + 16 * i], tile[l4 + 1][lr + 16 * i], tile[l4 + 2][lr + 16 * i], tile[l4 + 3][lr + 16 * i]};
+                if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst_t + (int64_t)c * d.rows + r) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                else *(f32x4*)(dst_t + (int64_t)c * d.rows + r) = v;
+            }
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        const bool ok = r < d.rows && c < d.cols;
+        const float v = ok ? d.src[(int64_t)r * d.cols + c] : 0.f;
+        tile[i][tx] = v;
+        if (ok && dst) dst[(int64_t)r * d.cols + c] = from_f32<TO>(v);
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < d.cols && r < d.rows) dst_t[(int64_t)c * d.rows + r] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t n,
                                        float* __restrict__ out, int accumulate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1095,6 +1162,15 @@ extern "C" int pa_transpose(const void* in, int in_dtype, int R, int C, int ldi,
     else if (in_dtype == PA_BF16 && out_dtype == PA_F32) PA_TR(bf16, float);
     else return PA_EINVAL;
 #undef PA_TR
+    return check_launch();
+}
+
+extern "C" int pa_stage_weights(const pa_stage_desc* descs, int n_desc, int total_tiles, int dtype, void* stream) {
+    if (!descs || n_desc <= 0 || total_tiles <= 0) return PA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PA_BF16) hipLaunchKernelGGL(stage_weights_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, descs, n_desc);
+    else if (dtype == PA_F32) hipLaunchKernelGGL(stage_weights_kernel<float>, dim3(total_tiles), dim3(256), 0, st, descs, n_desc);
+    else return PA_EINVAL;
     return check_launch();
 }
 

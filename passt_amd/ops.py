@@ -73,6 +73,27 @@ def transpose(x, out_dtype, ldo=None, out=None):
     return out
 
 
+def make_stage_table(entries, device):
+    """entries: [(src f32 [R][C] contiguous, dst or None, dst_t or None)] -> (device table, n, total_tiles) for
+    stage_weights; the tensors must stay alive (and in place) for as long as the table is used."""
+    import numpy as np
+    from ._lib import StageDesc
+    arr = (StageDesc * len(entries))()
+    tiles = 0
+    for d, (src, dst, dst_t) in zip(arr, entries):
+        R, Cc = src.shape
+        assert src.is_contiguous() and src.dtype == torch.float32
+        d.src, d.dst, d.dst_t = _p(src), _p(dst), _p(dst_t)
+        d.rows, d.cols, d.tile_begin = R, Cc, tiles
+        tiles += ((R + 63) // 64) * ((Cc + 63) // 64)
+    host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+    return host.to(device), len(entries), tiles
+
+
+def stage_weights(table, n, tiles, dtype):
+    check(_lib.load().pa_stage_weights(_p(table), n, tiles, dtype, _stream()), "pa_stage_weights")
+
+
 # ---- layer norm ------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, eps, dtype, save_stats=True):
     M, D = x.shape

@@ -20,6 +20,7 @@ Patchout indices are drawn with the reference's own torch CPU RNG calls in the r
 (:513-553), hence bit-exact.
 """
 import math
+import os
 import warnings
 from collections import OrderedDict
 from functools import partial
@@ -146,18 +147,55 @@ def kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u):
 # --------------------------------------------------------------------------------------------
 class _Staged:
     """Per-dtype GEMM-ready copies of the weights (bf16 cast and/or transposes), re-made only when a
-    parameter changed (``_version`` bump by the optimizer / load_state_dict)."""
+    parameter changed (``_version`` bump by the optimizer / load_state_dict).  The first time a copy is
+    asked for it is made on its own; from then on a stale copy triggers ONE batched launch
+    (pa_stage_weights) that refreshes every known copy of that dtype in place -- after an optimizer step
+    all of them are stale together."""
 
     def __init__(self):
-        self.cache = {}
+        self.cache = {}     # (id(p), dtype, transposed) -> [version, tensor, p]
+        self.tables = {}    # dtype -> (signature, device table, n, tiles, keys)
         self.epoch = 0      # bumped by optimizers that update parameters through raw pointers
 
+    def _version(self, p):
+        return (p._version, p.data_ptr(), self.epoch)
+
+    def _refresh_all(self, dtype):
+        if os.environ.get("PASST_AMD_NO_BATCH_STAGE"):          # A/B knob: one launch per copy, as on first use
+            return False
+        groups = {}
+        for key, (ver, out, p) in self.cache.items():
+            if key[1] == dtype:
+                groups.setdefault(key[0], [p, None, None])[2 if key[2] else 1] = out
+        sig = tuple((pid, g[0].data_ptr(), None if g[1] is None else g[1].data_ptr(),
+                     None if g[2] is None else g[2].data_ptr()) for pid, g in groups.items())
+        tab = self.tables.get(dtype)
+        if tab is None or tab[0] != sig:
+            entries = []
+            for p, dst, dst_t in groups.values():
+                w2 = p.detach().reshape(p.shape[0], -1)
+                if not w2.is_contiguous():
+                    return False
+                entries.append((w2, dst, dst_t))
+            tab = self.tables[dtype] = (sig,) + ops.make_stage_table(entries, next(iter(groups.values()))[0].device)
+        ops.stage_weights(tab[1], tab[2], tab[3], dtype)
+        for key, ent in self.cache.items():
+            if key[1] == dtype:
+                ent[0] = self._version(ent[2])
+        return True
+
     def get(self, p, dtype, transposed):
+        if dtype == PA_F32 and not transposed:                  # used in place
+            w2 = p.detach().reshape(p.shape[0], -1)
+            return w2 if w2.is_contiguous() else w2.contiguous()
         key = (id(p), dtype, transposed)
-        ver = (p._version, p.data_ptr(), self.epoch)
+        ver = self._version(p)
         hit = self.cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None:
+            if hit[0] == ver:
+                return hit[1]
+            if hit[0][1] == ver[1] and self._refresh_all(dtype):     # same storage, new values: batched refresh
+                return hit[1]
         w = p.detach()
         w2 = w.reshape(w.shape[0], -1)
         if not w2.is_contiguous():
@@ -166,7 +204,8 @@ class _Staged:
             out = ops.transpose(w2, dtype)
         else:
             out = ops.convert(w2, dtype)
-        self.cache[key] = (ver, out)
+        self.cache[key] = [ver, out, p]
+        self.tables.pop(dtype, None)
         return out
 
 

@@ -402,3 +402,39 @@ def test_gather_scatter_rows():
     assert torch.equal(s.cpu(), ref)
     xb = rnd(20, 64, seed=73).to(torch.bfloat16).to(DEV)
     assert torch.equal(ops.gather_rows(xb, idx[:2]).cpu(), xb.cpu()[idx[:2].cpu().long()])
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+def test_stage_weights_batched(dt):
+    """One launch refreshes every straight / transposed weight copy: bit-identical to torch's cast + .t()."""
+    shapes = [(768, 768), (2304, 768), (70, 130), (64, 64), (527, 768), (3, 5), (768, 256)]
+    srcs = [rnd(r, c, seed=11 + i).to(DEV) for i, (r, c) in enumerate(shapes)]
+    entries = []
+    for i, w in enumerate(srcs):
+        dst = torch.full(w.shape, 7.0, device=DEV, dtype=TD[dt]) if i % 3 != 1 else None
+        dst_t = torch.full((w.shape[1], w.shape[0]), 7.0, device=DEV, dtype=TD[dt]) if i % 3 != 2 else None
+        entries.append((w, dst, dst_t))
+    table, n, tiles = ops.make_stage_table(entries, DEV)
+    ops.stage_weights(table, n, tiles, dt)
+    torch.cuda.synchronize()
+    for w, dst, dst_t in entries:
+        if dst is not None:
+            assert torch.equal(dst, w.to(TD[dt]))
+        if dst_t is not None:
+            assert torch.equal(dst_t, w.t().contiguous().to(TD[dt]))
+
+
+def test_staged_cache_batched_refresh_matches_single():
+    """_Staged: after a parameter update the batched refresh yields the same copies as first-use staging."""
+    from passt_amd.passt import _Staged
+    ps = [torch.nn.Parameter(rnd(96, 160, seed=31 + i).to(DEV)) for i in range(3)]
+    st = _Staged()
+    first = [(st.get(p, PA_BF16, False), st.get(p, PA_BF16, True)) for p in ps]
+    with torch.no_grad():
+        for p in ps:
+            p.mul_(1.5).add_(0.25)
+    again = [(st.get(p, PA_BF16, False), st.get(p, PA_BF16, True)) for p in ps]
+    for p, (a, at), (f, ft) in zip(ps, again, first):
+        assert a.data_ptr() == f.data_ptr() and at.data_ptr() == ft.data_ptr()     # refreshed in place
+        assert torch.equal(a, p.detach().to(torch.bfloat16))
+        assert torch.equal(at, p.detach().t().contiguous().to(torch.bfloat16))
