@@ -151,6 +151,81 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
     }
 }
 
+// f32-output epilogues (residual add, split-K partial) straight from the MFMA accumulator layout: register r of
+// a 32x32 block holds row acc_row(r) and column lane&31, so one dword per lane is already a 128-byte run per
+// row -- no LDS transposition at all.  Row bases are uniform (SGPR) + a fixed per-lane offset.  Residual rows
+// are requested two 32-row passes ahead of their use and before the stores of the pass in between (vmcnt
+// retires in order: a load queued behind a store waits for that store's acknowledge).
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_epilogue_f32_direct(const pa_gemm_args& a, f32x16 (&acc)[TM][2], const float* bias_row,
+                                                         int m0, int n0, int split, int wr, int wc, int lane) {
+    static_assert(EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL, "f32 outputs only");
+    constexpr bool RES = EPI == PA_EPI_RESID;
+    const int half = lane >> 5, nl = lane & 31;
+    const int mb = m0 + wr * (TM * 32);             // uniform: first row of this wave's tile
+    const int nb = n0 + wc * 64 + nl;               // this lane's column in block j = 0 (j = 1: + 32)
+    float b2[2] = {0.f, 0.f};
+    if constexpr (RES) {
+        if (bias_row) { b2[0] = bias_row[wc * 64 + nl]; b2[1] = bias_row[wc * 64 + 32 + nl]; }
+    }
+    float* outp = RES ? a.out_f32 : a.out_f32 + (int64_t)split * a.M * a.ldo32;
+    const bool full = mb + TM * 32 <= a.M && n0 + wc * 64 + 64 <= a.N && !(RES && a.row_mod > 0);
+    if (full) {
+        // one uniform base per tile (SGPRs) + 32-bit per-lane offsets; the row term of the offset is uniform and
+        // added on the fly, so nothing per row has to stay live
+        const char* rbase = RES ? (const char*)a.resid + (int64_t)mb * a.ldr * 4 : nullptr;
+        char* obase = (char*)outp + (int64_t)mb * a.ldo32 * 4;
+        const uint32_t vo = (uint32_t)(4 * half * a.ldo32 + nb) * 4u, ldo4 = (uint32_t)a.ldo32 * 4u;
+        const uint32_t vr = RES ? (uint32_t)(4 * half * a.ldr + nb) * 4u : 0u, ldr4 = RES ? (uint32_t)a.ldr * 4u : 0u;
+        constexpr int U = 2 * TM, DEPTH = 3;          // units of one 32x32 block (16 rows x 1 dword per lane)
+        float x[DEPTH][16];
+        auto load_unit = [&](int slot, int u) {
+            if constexpr (RES) {
+                const int i = u >> 1, j = u & 1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    x[slot][r] = *(const float*)(rbase + (vr + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldr4 + j * 128));
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < DEPTH && u < U; ++u) load_unit(u, u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u >> 1, j = u & 1;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + b2[j] + (RES ? x[u % DEPTH][r] : 0.f);
+            if (u + DEPTH < U) load_unit(u % DEPTH, u + DEPTH);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *(float*)(obase + (vo + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo4 + j * 128)) = v[r];
+        }
+    } else {   // edge tiles and the row-remapped (patch embedding) form: per-element checks
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + i * 32 + acc_row(r, lane);
+                if (m >= a.M) continue;
+                int64_t rrow = m, orow = m;
+                if constexpr (RES) {
+                    if (a.row_mod > 0) {
+                        rrow = m % a.row_mod;
+                        orow = (int64_t)(m / a.row_mod) * a.out_batch_rows + a.out_row_off + rrow;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = nb + j * 32;
+                    if (n >= a.N) continue;
+                    float v = acc[i][j][r] + b2[j];
+                    if constexpr (RES) v += a.resid[rrow * a.ldr + n];
+                    outp[orow * a.ldo32 + n] = v;
+                }
+            }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most `k * PER` of this wave's global->LDS copies are still in flight (k = 0..3)
 template <int PER> __device__ __forceinline__ void wait_vm_groups(int k) {
@@ -499,18 +574,24 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         // slabs go into the ring slot that was read last (gbuf now names the one holding the next item's tile 0)
         float* slab = (float*)(wave < G::SLABS_IN_STAGE ? smem + (gbuf ^ 1) * STAGE_BYTES + wave * SLAB_BYTES
                                                         : smem + 2 * STAGE_BYTES + (wave - G::SLABS_IN_STAGE) * SLAB_BYTES);
-        float bias8[8];
+        if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
+            (void)slab;
+            gemm_epilogue_f32_direct<EPI, TM>(a, acc, HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr, cur_m0,
+                                              cur_n0, cur_split, wr, wc, lane);
+        } else {
+            float bias8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-        if constexpr (HAS_BIAS) {
-            if (a.bias) {
-                const float* brow = (const float*)(smem + G::BIAS_OFF) + wc * 64 + (lane & 7) * 8;
-                const f32x4 lo = *(const f32x4*)brow, hi = *(const f32x4*)(brow + 4);
+            for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+            if constexpr (HAS_BIAS) {
+                if (a.bias) {
+                    const float* brow = (const float*)(smem + G::BIAS_OFF) + wc * 64 + (lane & 7) * 8;
+                    const f32x4 lo = *(const f32x4*)brow, hi = *(const f32x4*)(brow + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bias8[e] = lo[e]; bias8[4 + e] = hi[e]; }
+                    for (int e = 0; e < 4; ++e) { bias8[e] = lo[e]; bias8[4 + e] = hi[e]; }
+                }
             }
+            gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8);
         }
-        gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8);
         if (!have_next) break;
         // (re)derive the DMA cursor of the item just started: cheaper than carrying it through the epilogue
         ++round;
@@ -878,9 +959,7 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    __syncthreads();
-    const float nobias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    gemm_epilogue<bf16, PA_EPI_PARTIAL, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, nobias);
+    gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, blockIdx.y, wr, wc, lane);
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
