@@ -11,6 +11,7 @@
 // LDS image is lane-linear, so the bank-conflict XOR swizzle is applied on the per-lane SOURCE
 // address and again on the ds_read_b128 address (guide rule 21).
 #include <algorithm>
+#include <type_traits>
 
 #include "pa_mma.h"
 
@@ -919,18 +920,44 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
 
-    for (int t = 0; t < nsteps; ++t) {
-        const char* sA = smem + (t & 1) * STAGE_BYTES;
-        const char* sB = sA + OP_BYTES;
-        const bool more = t + 1 < nsteps;
+    // per-lane fragment addresses inside a stage (see tn2_frag: the +4-row partner is +2048 bytes, a 16-token
+    // phase +8192, and the swizzle term only depends on the lane)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t offA[TM], offB[2];
+    {
+        const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+        const int r1 = h * 8 + (p >> 2);
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
+        for (int i = 0; i < TM; ++i) {
+            const int col = wr * 128 + i * 32 + g * 16 + (p & 3) * 4;
+            offA[i] = lds0 + tn2_swz(r1, col >> 3) + (col & 7) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wc * 64 + j * 32 + g * 16 + (p & 3) * 4;
+            offB[j] = lds0 + OP_BYTES + tn2_swz(r1, col >> 3) + (col & 7) * 2;
+        }
+    }
+    auto join = [](bf16x4 lo, bf16x4 hi) {
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    };
+
+    for (int t = 0; t < nsteps; ++t) {
+        const uint32_t sb = (t & 1) * STAGE_BYTES;
+        const bool more = t + 1 < nsteps;
+        auto phase = [&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
             // ---------------- L segment: fragments of 16 tokens ----------------
             bf16x8 fa[TM], fb[2];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = tn2_frag(sA, ph, wr * 128 + i * 32, lane);
+            for (int i = 0; i < TM; ++i)
+                fa[i] = join(lds_tr16_asm<ph * 8192>(offA[i] + sb), lds_tr16_asm<ph * 8192 + 2048>(offA[i] + sb));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = tn2_frag(sB, ph, wc * 64 + j * 32, lane);
+            for (int j = 0; j < 2; ++j)
+                fb[j] = join(lds_tr16_asm<ph * 8192>(offB[j] + sb), lds_tr16_asm<ph * 8192 + 2048>(offB[j] + sb));
             if (more) {
                 if (ph == 0) dmaA((t + 1) & 1, t + 1);
                 if (ph == 1) dmaB((t + 1) & 1, t + 1);
@@ -956,7 +983,11 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-        }
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, blockIdx.y, wr, wc, lane);

@@ -86,4 +86,17 @@ __device__ __forceinline__ bf16x4 lds_tr16(const char* lds_ptr) {
     return o;
 }
 
+// The same read as inline asm with an immediate offset.  The compiler cannot tell which LDS bytes the intrinsic
+// form touches, so with an LDS-DMA (global_load_lds) in flight it puts s_waitcnt vmcnt(0) in front of every such
+// read -- which serialises a prefetch against the reads of the tile being consumed.  This form is invisible
+// to that analysis: the CALLER must s_waitcnt lgkmcnt(0) before using the result and must order the read
+// against the DMA that filled the tile itself (both kernels that use it do so with explicit waits + barriers).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr16_asm(uint32_t lds_addr) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return __builtin_bit_cast(bf16x4, r);
+}
+
 }  // namespace pa
