@@ -158,7 +158,16 @@ typedef struct {
                             * (benchmarking / autotuning), pa_gemm_nt bf16: 1 = 128x128 tile, 4 waves, 2 workgroups/CU;
                             * 2 = 256x256 lockstep; 6 / 7 / 8 = role-split 256x256 / 192x256 / 128x256 (8 waves,
                             * staggered wave groups).  pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256. */
+    /* PA_EPI_DGELU only, optional: colsum_out[n] = (colsum_accumulate ? colsum_out[n] : 0) + sum_m out[m][n] (of the
+     * f32 values, before rounding) -- the bias gradient of the Linear whose pre-activation is `aux` (fc1.bias),
+     * reduced inside the epilogue instead of by a separate pass over out_lp.  colsum_ws: f32 workspace of
+     * pa_gemm_colsum_ws_floats(M, N) elements.  NULL colsum_out: not computed. */
+    float* colsum_out;
+    float* colsum_ws;
+    int32_t colsum_accumulate;
+    int32_t reserved;
 } pa_gemm_args;
+int64_t pa_gemm_colsum_ws_floats(int M, int N);
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
 /* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major
  * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over

@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("lda", i32), ("ldb", i32), ("A", vp), ("B", vp), ("bias", vp), ("resid", vp),
                 ("ldr", i32), ("row_mod", i32), ("out_batch_rows", i32), ("out_row_off", i32),
                 ("aux", vp), ("ldaux", i32), ("out_f32", vp), ("ldo32", i32), ("out_lp", vp),
-                ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32), ("tune", i32)]
+                ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32), ("tune", i32),
+                ("colsum_out", vp), ("colsum_ws", vp), ("colsum_accumulate", i32), ("reserved", i32)]
 
 
 class StageDesc(C.Structure):          # == pa_stage_desc
@@ -49,6 +50,7 @@ SIGNATURES = {
     "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
     "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "pa_gemm_colsum_ws_floats": (i64, [i32, i32]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_colsum_ws_floats": (i64, [i32, i32]),

@@ -36,6 +36,10 @@ static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
 //   * each pass issues its stores back to back with no wait in between.
 static constexpr int SLAB_BYTES = 32 * 68 * 4;     // 8704 per wave
 
+// PA_EPI_DGELU with colsum_out: the epilogue left one row of column sums per 32*TM-row wave tile in colsum_ws
+// ([rows][N]); this adds them up (defined next to colsum_f32_kernel)
+static int finish_gemm_colsum(const pa_gemm_args& a, int rows, hipStream_t st);
+
 template <int EPI, int TM> __host__ __device__ constexpr int aux_depth() {
     return EPI == PA_EPI_DGELU ? TM : (EPI == PA_EPI_RESID ? (TM <= 3 ? TM : 2) : 0);
 }
@@ -56,7 +60,8 @@ __device__ __forceinline__ void load_bias8(const pa_gemm_args& a, int n0, int wc
 
 template <typename T, int EPI, int TM = 2>
 __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&acc)[TM][2], float* slab, int m0,
-                                              int n0, int split, int wr, int wc, int lane, const float (&bias8)[8]) {
+                                              int n0, int split, int wr, int wc, int lane, const float (&bias8)[8],
+                                              int colsum_row = 0) {
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
     const int ncol = n0 + wc * 64 + ecol;
     const bool colok = ncol < a.N;               // N % 8 == 0: the lane's 8-vector is all in or all out
@@ -100,6 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
     };
 #pragma unroll
     for (int i = 0; i < P && i < TM; ++i) load_aux(i, i);
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // PA_EPI_DGELU: column sums of the outputs
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -126,6 +132,10 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
                     for (int e = 0; e < 8; ++e) v[it][e] += x[e];
                 } else {
                     mul_gelu_grad8<T>(v[it], x);
+                    if (pass_row(i, it) >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) csum[e] += v[it][e];
+                    }
                 }
             }
             if (i + P < TM) load_aux(i % P, i + P);    // the slot was consumed just above
@@ -148,6 +158,17 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
             } else {  // PA_EPI_PARTIAL
                 store8<float>(a.out_f32 + ((int64_t)split * a.M + m) * a.ldo32 + ncol, v[it]);
             }
+        }
+    }
+    if constexpr (EPI == PA_EPI_DGELU) {
+        if (a.colsum_out) {     // rows of this wave's tile: lanes with equal (lane & 7) hold the same 8 columns
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                csum[e] += __shfl_xor(csum[e], 8, 64);
+                csum[e] += __shfl_xor(csum[e], 16, 64);
+                csum[e] += __shfl_xor(csum[e], 32, 64);
+            }
+            if (lane < 8 && colok) store8<float>(a.colsum_ws + (int64_t)colsum_row * a.N + ncol, csum);
         }
     }
 }
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
         if (++buf == STAGES) buf = 0;
     }
     __syncthreads();  // every wave is done reading the operand tiles; LDS is reused by the slabs
-    gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8);
+    gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8, tm * WM + wr);
 }
 
 template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
@@ -389,7 +410,9 @@ static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
     (void)attr_set;
     hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
                        tiles_m, tiles_n, nwg, per);
-    return check_launch();
+    const int rc = check_launch();
+    if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * WM, st);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -591,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                     for (int e = 0; e < 4; ++e) { bias8[e] = lo[e]; bias8[4 + e] = hi[e]; }
                 }
             }
-            gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8);
+            gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8, (cur_m0 / TBM) * 2 + wr);
         }
         if (!have_next) break;
         // (re)derive the DMA cursor of the item just started: cheaper than carrying it through the epilogue
@@ -622,7 +645,9 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     (void)attr_set;
     hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(std::min(total, 256)), dim3(512), G::LDS, st, a, tiles_m,
                        tiles_n, nwg, per, total);
-    return check_launch();
+    const int rc = check_launch();
+    if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
+    return rc;
 }
 
 // Variant choice when pa_gemm_args.tune == 0: minimise  rounds x tile_time  with
@@ -1244,6 +1269,7 @@ extern "C" int pa_gemm_nt(const pa_gemm_args* a, void* stream) {
     if (a->out_f32 && a->ldo32 % 4) return PA_EUNSUPPORTED;
     if (a->resid && a->ldr % 4) return PA_EUNSUPPORTED;
     if (a->aux && a->ldaux % 8) return PA_EUNSUPPORTED;
+    if (a->colsum_out && (a->epilogue != PA_EPI_DGELU || !a->colsum_ws)) return PA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == PA_BF16) return dispatch_gemm<bf16>(*a, st);
     if (a->dtype == PA_F32) return dispatch_gemm<float>(*a, st);
@@ -1301,6 +1327,15 @@ extern "C" int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float*
     else return PA_EINVAL;
     return check_launch();
 }
+
+static int pa::finish_gemm_colsum(const pa_gemm_args& a, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(a.N, 64)), dim3(256), 0, st, a.colsum_ws, rows, a.N, a.N, a.colsum_out,
+                       a.colsum_accumulate);
+    return check_launch();
+}
+
+// rows of colsum_ws: two wave-tile rows per workgroup tile, tiles of >= 128 rows in every variant
+extern "C" int64_t pa_gemm_colsum_ws_floats(int M, int N) { return (M <= 0 || N <= 0) ? 0 : 2 * cdiv(M, 128) * (int64_t)N; }
 
 extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate,
                              void* stream) {

@@ -121,8 +121,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
 
 # ---- GEMM ------------------------------------------------------------------------------------
 def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
-            out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None):
-    """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h."""
+            out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None,
+            colsum_out=None, colsum_ws=None, colsum_accumulate=False):
+    """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h.  EPI_DGELU can also return the
+    column sums of its output (colsum_out [N] f32; colsum_ws from gemm_colsum_ws)."""
     a = GemmArgs()
     a.dtype, a.epilogue = dtype, epilogue
     a.M = A.shape[0] if M is None else M
@@ -144,6 +146,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
     a.tune = GEMM_TUNE
+    a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out), _p(colsum_ws), int(colsum_accumulate)
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
         return
@@ -152,6 +155,14 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
     ev1.record()
     GEMM_PROFILE.setdefault(_EPI_NAME[epilogue], []).append((ev0, ev1, 2.0 * a.M * a.N * a.K))
+
+
+def gemm_colsum_ws(M, N, device, ws=None):
+    """f32 workspace for gemm_nt(..., colsum_out=...); reuses `ws` when it is large enough."""
+    n = _lib.load().pa_gemm_colsum_ws_floats(M, N)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, device=device, dtype=torch.float32)
+    return ws
 
 
 def linear(x_lp, W_lp, bias, dtype):

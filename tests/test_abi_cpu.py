@@ -45,9 +45,10 @@ def test_ctypes_structs_match_the_c_layout():
 #include <stddef.h>
 #include "passt_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
          offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
-         offsetof(pa_gemm_args, tune), sizeof(pa_mel_params));
+         offsetof(pa_gemm_args, tune), sizeof(pa_mel_params), offsetof(pa_gemm_args, colsum_out),
+         offsetof(pa_gemm_args, colsum_accumulate), sizeof(pa_stage_desc));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -56,7 +57,8 @@ int main(void) {
         out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
     G = _lib.GemmArgs
     got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
-           G.tune.offset, ctypes.sizeof(_lib.MelParams)]
+           G.tune.offset, ctypes.sizeof(_lib.MelParams), G.colsum_out.offset, G.colsum_accumulate.offset,
+           ctypes.sizeof(_lib.StageDesc)]
     assert got == [int(v) for v in out]
 
 

@@ -438,3 +438,34 @@ def test_staged_cache_batched_refresh_matches_single():
         assert a.data_ptr() == f.data_ptr() and at.data_ptr() == ft.data_ptr()     # refreshed in place
         assert torch.equal(a, p.detach().to(torch.bfloat16))
         assert torch.equal(at, p.detach().t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("tune", [0, 1, 6, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2 * 474, 3072, 768), (1000, 768, 256)])
+def test_gemm_dgelu_fused_bias_gradient(dt, tune, M, N, K):
+    """EPI_DGELU can return the column sums of its output (the fc1.bias gradient) from the same epilogue."""
+    if dt == PA_F32 and tune != 0:
+        pytest.skip("the f32 parity path has one tile variant")
+    A = rnd(M, K, seed=40).to(TD[dt]).to(DEV)
+    Bm = rnd(N, K, seed=41, scale=0.3).to(TD[dt]).to(DEV)
+    aux = rnd(M, N, seed=42, scale=2.0).to(TD[dt]).to(DEV)
+    dg = torch.empty(M, N, device=DEV, dtype=TD[dt])
+    db = torch.full((N,), 3.0, device=DEV)
+    ws = ops.gemm_colsum_ws(M, N, DEV)
+    ops.GEMM_TUNE = tune
+    try:
+        ops.gemm_nt(A, Bm, dt, EPI_DGELU, aux=aux, out_lp=dg, colsum_out=db, colsum_ws=ws)
+        torch.cuda.synchronize()
+        a64 = aux.double().cpu()
+        gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+        ref = (A.double().cpu() @ Bm.double().cpu().T) * gp
+        assert rel_err(dg, ref) < tol(dt, 3e-5, 1.2e-2)
+        e = rel_err(db, ref.sum(0))
+        record(f"gemm_dgelu_colsum[{dt},{tune},{M}x{N}x{K}]", rel=e)
+        assert e < tol(dt, 3e-5, 2e-3)
+        db2 = db.clone()
+        ops.gemm_nt(A, Bm, dt, EPI_DGELU, aux=aux, out_lp=dg, colsum_out=db2, colsum_ws=ws, colsum_accumulate=True)
+        assert rel_err(db2, 2 * ref.sum(0)) < tol(dt, 3e-5, 2e-3)
+    finally:
+        ops.GEMM_TUNE = 0
