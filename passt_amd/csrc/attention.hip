@@ -70,14 +70,18 @@ __device__ __forceinline__ typename Frag<T>::type row_frag(const char* lds, int 
 //   bf16: rows rbase + 16s + 4h + {0..3} and + 8 more;  f32: rows rbase + 8s + 4h + {0..3}
 template <typename T>
 __device__ __forceinline__ typename Frag<T>::type col_frag(const char* lds, int rbase, int s, int d0, int lane);
+// bf16: ISSUED ONLY (asm reads, see lds_tr16_asm): the fragment is valid after col_settle<>() on it.  With the
+// intrinsic form the compiler drains the LDS-DMA of the NEXT tile (s_waitcnt vmcnt(0)) in front of the first
+// column read of every tile, i.e. the prefetch never overlaps anything.
 template <>
 __device__ __forceinline__ bf16x8 col_frag<bf16>(const char* lds, int rbase, int s, int d0, int lane) {
     const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
     const int r1 = rbase + 16 * s + 4 * h + (p >> 2);
     const int d = d0 + g * 16 + (p & 3) * 4;                   // first of this lane's 4 source elements
     const int within = (d & 7) * 2;
-    const bf16x4 lo = lds_tr16(lds + swz128(r1, d >> 3) + within);
-    const bf16x4 hi = lds_tr16(lds + swz128(r1 + 8, d >> 3) + within);
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const bf16x4 lo = lds_tr16_asm<0>(base + swz128(r1, d >> 3) + within);
+    const bf16x4 hi = lds_tr16_asm<0>(base + swz128(r1 + 8, d >> 3) + within);
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -93,6 +97,16 @@ __device__ __forceinline__ f32x4 col_frag<float>(const char* lds, int rbase, int
         f[e] = *(const float*)(lds + swz256(row, d >> 2) + (d & 3) * 4);
     }
     return f;
+}
+
+// Wait until at most PENDING younger LDS operations are outstanding and tie the fragments to the wait, so no use
+// of them can be scheduled above it.  f32 fragments come from plain loads the compiler tracks itself: no-op.
+template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b) {
+    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PENDING));
+}
+template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b, F& c, F& d) {
+    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8))
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(PENDING));
 }
 
 // Transposed store of two 32x32 accumulator tiles acc[db] (lane = owned row, register = d) as rows of
@@ -206,16 +220,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
-        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        // O^T[d][q] += V^T[d][key] P^T[key][q]; the V column fragments of step i+1 are in flight under the
+        // MFMAs of step i
+        {
+            constexpr int NS = 2 * AccSteps<T>::N;
+            typename Frag<T>::type vfr[2][2];
+            auto issue = [&](int slot, int step) {
+                const int kb = step / AccSteps<T>::N, st = step % AccSteps<T>::N;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int db = 0; db < 2; ++db) vfr[slot][db] = col_frag<T>(sV, kb * 32, st, db * 32, lane);
+            };
+            issue(0, 0);
 #pragma unroll
-            for (int st = 0; st < AccSteps<T>::N; ++st) {
+            for (int step = 0; step < NS; ++step) {
+                const int kb = step / AccSteps<T>::N, st = step % AccSteps<T>::N;
+                if (step + 1 < NS) {
+                    issue((step + 1) & 1, step + 1);
+                    col_settle<4>(vfr[step & 1][0], vfr[step & 1][1]);
+                } else {
+                    col_settle<0>(vfr[step & 1][0], vfr[step & 1][1]);
+                }
                 const typename Frag<T>::type pf = acc_frag<T>(s[kb], st);
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    mma32<T>(oacc[db], col_frag<T>(sV, kb * 32, st, db * 32, lane), pf);
+                for (int db = 0; db < 2; ++db) mma32<T>(oacc[db], vfr[step & 1][db], pf);
             }
+        }
     }
     __syncthreads();   // tiles are dead; reuse LDS for the transposed store
     // only the first nq queries of every sequence are produced; o / lse are compact (nq rows per sequence)
@@ -305,13 +334,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
                     if (qt * TROWS + qb * 32 + acc_row(r, lane) >= nq) { sa[r] = 0.f; dpa[r] = 0.f; }
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+            {
+                constexpr int NS = AccSteps<T>::N;
+                typename Frag<T>::type cf[2][4];
+                auto issue = [&](int slot, int st) {
 #pragma unroll
-            for (int st = 0; st < AccSteps<T>::N; ++st) {
-                const typename Frag<T>::type pf = acc_frag<T>(sa, st), dsf = acc_frag<T>(dpa, st);
+                    for (int db = 0; db < 2; ++db) {
+                        cf[slot][db] = col_frag<T>(sDO, qb * 32, st, db * 32, lane);
+                        cf[slot][2 + db] = col_frag<T>(sQ, qb * 32, st, db * 32, lane);
+                    }
+                };
+                issue(0, 0);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    mma32<T>(dv[db], col_frag<T>(sDO, qb * 32, st, db * 32, lane), pf);
-                    mma32<T>(dk[db], col_frag<T>(sQ, qb * 32, st, db * 32, lane), dsf);
+                for (int st = 0; st < NS; ++st) {
+                    if (st + 1 < NS) {
+                        issue((st + 1) & 1, st + 1);
+                        col_settle<8>(cf[st & 1][0], cf[st & 1][1], cf[st & 1][2], cf[st & 1][3]);
+                    } else {
+                        col_settle<0>(cf[st & 1][0], cf[st & 1][1], cf[st & 1][2], cf[st & 1][3]);
+                    }
+                    const typename Frag<T>::type pf = acc_frag<T>(sa, st), dsf = acc_frag<T>(dpa, st);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        mma32<T>(dv[db], cf[st & 1][db], pf);
+                        mma32<T>(dk[db], cf[st & 1][2 + db], dsf);
+                    }
                 }
             }
         }
@@ -410,12 +457,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                     if (kt * TROWS + kb * 32 + acc_row(r, lane) >= N) dpa[r] = 0.f;
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            {
+                constexpr int NS = AccSteps<T>::N;
+                typename Frag<T>::type cf[2][2];
+                auto issue = [&](int slot, int st) {
 #pragma unroll
-            for (int st = 0; st < AccSteps<T>::N; ++st) {
-                const typename Frag<T>::type dsf = acc_frag<T>(dpa, st);
+                    for (int db = 0; db < 2; ++db) cf[slot][db] = col_frag<T>(sK, kb * 32, st, db * 32, lane);
+                };
+                issue(0, 0);
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    mma32<T>(dq[db], col_frag<T>(sK, kb * 32, st, db * 32, lane), dsf);
+                for (int st = 0; st < NS; ++st) {
+                    if (st + 1 < NS) {
+                        issue((st + 1) & 1, st + 1);
+                        col_settle<4>(cf[st & 1][0], cf[st & 1][1]);
+                    } else {
+                        col_settle<0>(cf[st & 1][0], cf[st & 1][1]);
+                    }
+                    const typename Frag<T>::type dsf = acc_frag<T>(dpa, st);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) mma32<T>(dq[db], cf[st & 1][db], dsf);
+                }
             }
         }
     }
