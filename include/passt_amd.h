@@ -274,11 +274,26 @@ int pa_ce_mixup_fwd_bwd(const float* logits, const int32_t* target, const int32_
 /* ex_audioset.py:175-177 / helpers/mixup.py: out[b] = x[b]*lam[b] + x[perm[b]]*(1-lam[b]) */
 int pa_mixup(const float* x, const int32_t* perm, const float* lam, float* out, int B,
              int64_t per_sample, void* stream);
+/* Waveform-side augmentation of one batch, ahead of the front end.  What the reference's data
+ * pipeline does per clip on CPU workers, in its order: gain (audioset/dataset.py:102-112, amp = 10^(dB/20)),
+ * pad_or_truncate to L samples (:73-78), roll (:315-329: out[t] = in[(t - shift) mod L]) and waveform mixup
+ * (MixupDataset.__getitem__ :123-137: both clips mean-centred, w = max(lam, 1 - lam), out = w a + (1 - w) b).
+ * The random parameters are drawn by the caller (host RNG, reference order).
+ *   x: [B][ldx] f32 raw clips; len[b] valid samples (NULL: ldx); amp[b] (NULL: 1); shift[b] (NULL: 0);
+ *   partner[b] >= 0: mix clip b with clip partner[b] using lam[b]; < 0: not mixed (NULL: no mixing at all).
+ *   out: [B][L] f32 (the (B, 1, L) batch the training step takes); ws: f32 workspace of B floats.
+ * The reference's last `x - x.mean()` of a mix is omitted: the mean of two centred signals is f32 rounding
+ * noise (< 1e-7 of the amplitude). */
+int pa_wave_augment(const float* x, int B, int64_t ldx, const int32_t* len, const float* amp, const int32_t* shift,
+                    const int32_t* partner, const float* lam, float* ws, float* out, int64_t L, void* stream);
 /* torch.optim.AdamW (ex_audioset.py:104-109) on one flat f32 parameter buffer */
 int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, void* stream);
 /* torch.optim.SGD lr only (ex_audioset.py:392 model_speed_test) */
 int pa_sgd(float* p, const float* g, int64_t n, float lr, void* stream);
+/* Stochastic weight averaging step on flat buffers (helpers/swa_callback.py:246-268, update_parameters + avg_fn):
+ * num_averaged == 0: avg = p;  else avg += (p - avg) / (num_averaged + 1).  The caller increments the count. */
+int pa_swa_update(float* avg, const float* p, int64_t n, int num_averaged, void* stream);
 
 #ifdef __cplusplus
 }

@@ -134,3 +134,35 @@ def build_reference_passt(cfg: dict, state_dict: dict):
 def run_silently(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
+
+
+def import_reference_file(relpath: str):
+    """Load ONE reference source file (e.g. ``helpers/ramp.py``, ``helpers/mixup.py``) as an anonymous module, with
+    the ``ba3l`` stub in place while it executes.  Used to pin small restatements (LR ramps, SWA formula)."""
+    import importlib.util
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+
+    class Ingredient:
+        def __init__(self, path):
+            self.path = path
+
+        def add_config(self, **kw):
+            pass
+
+        def command(self, f=None, **kw):
+            return f if f is not None else (lambda g: g)
+
+    stubs = {"ba3l": _mod("ba3l"), "ba3l.ingredients": _mod("ba3l.ingredients"),
+             "ba3l.ingredients.ingredient": _mod("ba3l.ingredients.ingredient", Ingredient=Ingredient)}
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_file_" + relpath.replace("/", "_").replace(".", "_"),
+                                                      os.path.join(REFERENCE_ROOT, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(mod)
+    finally:
+        for k in stubs:
+            if getattr(sys.modules.get(k), "__spec__", None) is None:
+                sys.modules.pop(k, None)
+    return mod

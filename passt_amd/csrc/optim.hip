@@ -50,6 +50,60 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, i
         p[i] -= lr * g[i];
 }
 
+// mean over the L samples of the padded / truncated, gain-scaled clip; one 1024-thread block per clip
+__global__ __launch_bounds__(1024) void wave_mean_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ len,
+                                                         const float* __restrict__ amp, float* __restrict__ mean, int64_t L) {
+    __shared__ float part[16];
+    const int b = blockIdx.x;
+    const int64_t n = min((int64_t)(len ? len[b] : ldx), L);
+    const float* xb = x + (int64_t)b * ldx;
+    float s = 0.f;
+    for (int64_t t = threadIdx.x; t < n; t += 1024) s += xb[t];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? part[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) mean[b] = v * (amp ? amp[b] : 1.f) / (float)L;
+    }
+}
+
+__global__ __launch_bounds__(256) void wave_mix_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ len,
+                                                       const float* __restrict__ amp, const int32_t* __restrict__ shift,
+                                                       const int32_t* __restrict__ partner, const float* __restrict__ lam,
+                                                       const float* __restrict__ mean, float* __restrict__ out, int64_t L) {
+    const int b = blockIdx.y;
+    const int p = partner ? partner[b] : -1;
+    auto clip = [&](int c, int64_t t) {             // sample t of clip c after gain, pad/truncate and roll
+        int64_t src = t - (shift ? shift[c] : 0);
+        src %= L;
+        if (src < 0) src += L;
+        const int64_t n = min((int64_t)(len ? len[c] : ldx), L);
+        return src < n ? x[(int64_t)c * ldx + src] * (amp ? amp[c] : 1.f) : 0.f;
+    };
+    const float l = p >= 0 ? fmaxf(lam[b], 1.f - lam[b]) : 1.f;
+    const float mb = p >= 0 ? mean[b] : 0.f, mp = p >= 0 ? mean[p] : 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < L; t += (int64_t)gridDim.x * blockDim.x) {
+        float v = clip(b, t);
+        if (p >= 0) v = (v - mb) * l + (clip(p, t) - mp) * (1.f - l);
+        out[(int64_t)b * L + t] = v;
+    }
+}
+
+__global__ void swa_kernel(float* __restrict__ avg, const float* __restrict__ p, int64_t n4, int64_t n, float inv) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 a = ((f32x4*)avg)[i];
+        const f32x4 w = ((const f32x4*)p)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = inv == 1.0f ? w[e] : a[e] + (w[e] - a[e]) * inv;
+        ((f32x4*)avg)[i] = a;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        avg[i] = inv == 1.0f ? p[i] : avg[i] + (p[i] - avg[i]) * inv;
+}
+
 }  // namespace pa
 
 using namespace pa;
@@ -75,6 +129,30 @@ extern "C" int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     const int blocks = (int)std::min<int64_t>(cdiv(n, 256), 8192);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, sqrtf(bc2));
+    return check_launch();
+}
+
+extern "C" int pa_wave_augment(const float* x, int B, int64_t ldx, const int32_t* len, const float* amp, const int32_t* shift,
+                               const int32_t* partner, const float* lam, float* ws, float* out, int64_t L, void* stream) {
+    if (!x || !out || B <= 0 || ldx <= 0 || L <= 0 || (partner && (!lam || !ws))) return PA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (partner) {
+        hipLaunchKernelGGL(wave_mean_kernel, dim3(B), dim3(1024), 0, st, x, ldx, len, amp, ws, L);
+        const int rc = check_launch();
+        if (rc) return rc;
+    }
+    dim3 grid((unsigned)std::min<int64_t>(cdiv(L, 256 * 4), 1024), (unsigned)B);
+    hipLaunchKernelGGL(wave_mix_kernel, grid, dim3(256), 0, st, x, ldx, len, amp, shift, partner, lam, ws, out, L);
+    return check_launch();
+}
+
+extern "C" int pa_swa_update(float* avg, const float* p, int64_t n, int num_averaged, void* stream) {
+    if (!avg || !p || n <= 0 || num_averaged < 0) return PA_EINVAL;
+    const bool vec = (((uintptr_t)avg | (uintptr_t)p) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const int blocks = (int)std::min<int64_t>(cdiv(std::max<int64_t>(n4, 1), 256), 8192);
+    // the reference divides by (n + 1); a reciprocal multiply differs by <= 1 ulp of the increment
+    hipLaunchKernelGGL(swa_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg, p, n4, n, 1.0f / (float)(num_averaged + 1));
     return check_launch();
 }
 

@@ -429,9 +429,24 @@ def mixup(x, perm_i32, lam):
     return out
 
 
+def wave_augment(x, L, lengths=None, amp=None, shift=None, partner=None, lam=None):
+    """x [B][ldx] f32 raw clips -> [B][L]: gain, pad/truncate, roll, waveform mixup (pa_wave_augment)."""
+    B, ldx = x.shape
+    out = torch.empty((B, L), device=x.device, dtype=torch.float32)
+    ws = torch.empty(B, device=x.device, dtype=torch.float32) if partner is not None else None
+    check(_lib.load().pa_wave_augment(_p(x), B, x.stride(0), _p(lengths), _p(amp), _p(shift), _p(partner), _p(lam), _p(ws),
+                                      _p(out), L, _stream()), "pa_wave_augment")
+    return out
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
     check(_lib.load().pa_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _stream()),
           "pa_adamw")
+
+
+def swa_update(avg, p, num_averaged):
+    """avg = p if num_averaged == 0 else avg + (p - avg) / (num_averaged + 1), flat f32 buffers."""
+    check(_lib.load().pa_swa_update(_p(avg), _p(p), p.numel(), int(num_averaged), _stream()), "pa_swa_update")
 
 
 def sgd(p, g, lr):

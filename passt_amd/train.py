@@ -42,7 +42,13 @@ class TrainStep:
         self.v = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
         self.reducer = GradReducer(self.flat_g, [(n, p.numel()) for n, p in self.named], len(net.blocks), process_group)
         self.t = 0
+        self.base_lr = lr
         net.mark_params_updated()
+
+    def set_lr_factor(self, factor):
+        """Per-epoch LR schedule (ex_audioset.py:86-101): lr = base_lr * factor, e.g. from
+        schedule.exp_warmup_linear_down(5, 50, 50, 0.01)(epoch)."""
+        self.lr = self.base_lr * float(factor)
 
     def step(self, wave_or_spec, target):
         """wave (B,1,L) / (B,L) when a mel module was given, else a spectrogram (B,1,F,T).

@@ -126,6 +126,69 @@ def gen_frontend_case(name, case):
     print(name, tuple(out.shape), "range", float(out.min()), float(out.max()))
 
 
+WAVE_CASE = dict(seed=31, L=4000, lens=[4000, 2600, 5200, 4000, 3999], gain_db=[-7, 0, 3, 6, -2],
+                 shift=[0, 17, -50, 50, -1], partner=[2, -1, 0, 4, 3], lam=[0.31, 0.5, 0.77, 0.5, 0.05])
+
+
+def wave_inputs(case):
+    return [0.2 * detgen.uniform(case["seed"], f"raw{i}", (n,), -1.0, 1.0) + 0.05 * (i - 2) for i, n in enumerate(case["lens"])]
+
+
+def gen_wave_case():
+    """Runs the REAL bodies of pad_or_truncate / pydub_augment / get_roll_func / MixupDataset from
+    audioset/dataset.py (extracted with ast: the module needs av, h5py, librosa to import) on WAVE_CASE."""
+    import ast
+    src = open(os.path.join(ref_import.REFERENCE_ROOT, "audioset", "dataset.py")).read()
+    keep = []
+    for node in ast.parse(src).body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in ("pad_or_truncate", "pydub_augment",
+                                                                              "get_roll_func", "MixupDataset"):
+            node.decorator_list = []
+            keep.append(node)
+    ns = {"np": np, "torch": torch, "TorchDataset": object}
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(ast.Module(body=keep, type_ignores=[]), "<reference audioset/dataset.py>", "exec"), ns)
+    c = WAVE_CASE
+    raws = wave_inputs(c)
+
+    class Items:                                      # what AudioSetDataset.__getitem__ + roll_func hand over
+        def __len__(self):
+            return len(raws)
+
+        def __getitem__(self, i):
+            class OneDraw:                            # pydub_augment draws gain with torch.randint(2*7, (1,))
+                pass
+            saved = torch.randint
+            torch.randint = lambda *a, **k: torch.tensor([c["gain_db"][i] + 7])
+            try:
+                w = ns["pydub_augment"](raws[i], gain_augment=7, ir_augment=0)
+            finally:
+                torch.randint = saved
+            w = ns["pad_or_truncate"](w, c["L"]).reshape(1, -1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                x, _, y = ns["get_roll_func"](axis=1, shift=c["shift"][i])((w, f"clip{i}", np.eye(len(raws), dtype=np.float32)[i]))
+            return x, f"clip{i}", torch.as_tensor(y)
+
+    base = Items()
+    with contextlib.redirect_stdout(io.StringIO()):
+        mix = ns["MixupDataset"](base, beta=2, rate=0.5)
+    out, tgt = [], []
+    for b in range(len(raws)):
+        s_rand, s_randint, s_beta = torch.rand, torch.randint, np.random.beta
+        torch.rand = lambda *a, **k: torch.tensor([0.0 if c["partner"][b] >= 0 else 1.0])
+        torch.randint = lambda *a, **k: torch.tensor([max(c["partner"][b], 0)])
+        np.random.beta = lambda *a, **k: c["lam"][b]
+        try:
+            x, _, y = mix[b]
+        finally:
+            torch.rand, torch.randint, np.random.beta = s_rand, s_randint, s_beta
+        out.append(np.asarray(x, np.float32).reshape(-1))
+        tgt.append(np.asarray(y, np.float32))
+    np.savez_compressed(os.path.join(HERE, "wave_augment.npz"), out=np.stack(out), target=np.stack(tgt))
+    print("wave_augment", np.stack(out).shape, float(np.abs(np.stack(out)).max()))
+
+
 def gen_rng_kat():
     """SURVEY.md App. C KAT: the index path on torch CPU."""
     torch.manual_seed(123)
@@ -143,3 +206,4 @@ if __name__ == "__main__":
     for n, c in FRONTEND_CASES.items():
         gen_frontend_case(n, c)
     gen_rng_kat()
+    gen_wave_case()

@@ -469,3 +469,38 @@ def test_gemm_dgelu_fused_bias_gradient(dt, tune, M, N, K):
         assert rel_err(db2, 2 * ref.sum(0)) < tol(dt, 3e-5, 2e-3)
     finally:
         ops.GEMM_TUNE = 0
+
+
+def test_wave_augment_matches_reference_pipeline():
+    """pa_wave_augment (gain, pad/truncate, roll, waveform mixup) vs the golden outputs of the reference's own
+    dataset code and vs the oracle on a second, ragged case."""
+    from oracle import wave_oracle as W
+    from passt_amd.augment import WaveAugment
+    from tests.golden import make_golden as G
+    c = G.WAVE_CASE
+    raws = G.wave_inputs(c)
+    g = np.load(os.path.join(os.path.dirname(G.__file__), "wave_augment.npz"))
+    B, ldx = len(raws), max(len(r) for r in raws)
+    x = torch.zeros(B, ldx)
+    for b, r in enumerate(raws):
+        x[b, :len(r)] = torch.from_numpy(r)
+    aug = WaveAugment(clip_samples=c["L"])
+    params = (np.array(c["gain_db"]), np.array(c["shift"]), np.array(c["partner"]), np.array(c["lam"], np.float32))
+    wave, tgt = aug(x.to(DEV), torch.eye(B).to(DEV), torch.tensor([len(r) for r in raws], dtype=torch.int32), params)
+    assert wave.shape == (B, 1, c["L"])
+    e = float((wave[:, 0].cpu() - torch.from_numpy(g["out"])).abs().max())
+    record("wave_augment", abs=e)
+    assert e < 2e-7
+    assert float((tgt.cpu() - torch.from_numpy(g["target"])).abs().max()) < 1e-6
+    # drawn parameters, 10 s clips: against the oracle
+    torch.manual_seed(5)
+    np.random.seed(5)
+    aug = WaveAugment(clip_samples=320000)
+    raws = [(rnd(n, seed=60 + i, scale=0.3) + 0.01 * i).numpy() for i, n in enumerate([320000, 200000, 400000, 320000])]
+    x = torch.zeros(4, 400000)
+    for b, r in enumerate(raws):
+        x[b, :len(r)] = torch.from_numpy(r)
+    p = aug.draw(4)
+    wave, _ = aug(x.to(DEV), None, torch.tensor([len(r) for r in raws], dtype=torch.int32), p)
+    ref, _ = W.augment_batch(raws, list(p[0]), list(p[1]), list(p[2]), list(p[3]), 320000)
+    assert float((wave[:, 0].cpu() - torch.from_numpy(ref)).abs().max()) < 5e-7

@@ -268,3 +268,31 @@ def test_train_step_driver_matches_autograd_path():
             assert abs(loss1.item() - loss2.item()) < 1e-5, step
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert rel(p2.detach().cpu(), p1.detach().cpu()) < 2e-4, k
+
+
+def test_swa_matches_reference_update_rule():
+    """schedule.SWA (one fused kernel on the flat buffer) == helpers/swa_callback.py:246-268 applied per tensor
+    (restated here: avg = p for the first snapshot, then avg + (p - avg) / (n + 1)); copy_to() loads a deepcopy."""
+    import copy
+    from passt_amd.schedule import SWA
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=902)
+    net = build(case, "fp32").train()
+    ts = TrainStep(net, None, lr=1e-2, weight_decay=0.0, use_mixup=False)
+    swa = SWA(ts)
+    ref = None
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for n in range(4):
+        with torch.no_grad():                                  # stand-in for optimizer steps
+            ts.flat_p.add_(torch.randn(ts.flat_p.shape, generator=g).to(DEV) * 0.05)
+        snap = [p.detach().double().cpu().clone() for _, p in ts.named]
+        ref = snap if n == 0 else [a + (p - a) / (n + 1) for a, p in zip(ref, snap)]
+        swa.update()
+    assert swa.n_averaged == 4
+    avg_net = swa.copy_to(copy.deepcopy(net))
+    named = dict(avg_net.named_parameters())
+    for (name, _), r in zip(ts.named, ref):
+        assert rel(named[name].detach().cpu(), r) < 1e-6, name
+    # the trained module itself is untouched
+    for (name, p), s in zip(ts.named, snap):
+        assert torch.equal(p.detach().double().cpu(), s), name

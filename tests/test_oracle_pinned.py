@@ -155,3 +155,30 @@ def test_oracle_frontend_vs_live_reference():
         torch.manual_seed(3)
         got = O.mel_frontend(wave, training=training, fmin_aug_range=10, fmax_aug_range=2000)
         assert (ref - got).abs().max().item() < 2e-4
+
+
+def test_lr_schedule_matches_reference_ramp():
+    """passt_amd.schedule restates helpers/ramp.py; pinned to the live reference when it is mounted, and to the
+    closed form otherwise."""
+    import math
+    from passt_amd.schedule import exp_warmup_linear_down
+    f = exp_warmup_linear_down(5, 50, 50, 0.01)          # ex_audioset.py:86-101 defaults
+    assert f(0) == pytest.approx(math.exp(-5 * 0.9 ** 2)) and f(5) == 1.0 and f(50) == 1.0
+    assert f(75) == pytest.approx(0.01 + 0.99 * 0.5) and f(100) == pytest.approx(0.01) and f(130) == pytest.approx(0.01)
+    if ref_import.reference_available():
+        g = ref_import.import_reference_file("helpers/ramp.py").exp_warmup_linear_down(5, 50, 50, 0.01)
+        for e in list(range(0, 131)) + [0.25, 4.5, 50.5, 99.9]:
+            assert f(e) == pytest.approx(g(e), rel=1e-12, abs=1e-15)
+
+
+def test_wave_oracle_pinned_to_reference_outputs():
+    """oracle/wave_oracle.py vs tests/golden/wave_augment.npz (outputs of the reference's own pad_or_truncate /
+    pydub_augment / roll_func / MixupDataset bodies, see make_golden.gen_wave_case)."""
+    from oracle import wave_oracle as W
+    c = G.WAVE_CASE
+    g = np.load(os.path.join(os.path.dirname(G.__file__), "wave_augment.npz"))
+    out, w = W.augment_batch(G.wave_inputs(c), c["gain_db"], c["shift"], c["partner"], c["lam"], c["L"])
+    assert np.abs(out - g["out"]).max() < 2e-8
+    eye = np.eye(len(c["lens"]), dtype=np.float32)
+    tgt = np.stack([w[b] * eye[b] + (1 - w[b]) * eye[max(c["partner"][b], 0)] for b in range(len(w))])
+    assert np.abs(tgt - g["target"]).max() < 1e-7
