@@ -149,14 +149,22 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         if (lane == 0) y[(int64_t)b * C + c] = s + bc;
     }
 }
-__global__ void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
-                                     int B, int C, int D) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * D) return;
-    const int b = (int)(i / D), d = (int)(i % D);
+// dx[b][d] = sum_c dy[b][c] W[c][d]: workgroup = (64 columns d, one row b); the 4 waves split the classes (W rows read
+// as 256-byte runs, dy[b][c] is wave-uniform), partial sums meet in LDS
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                            float* __restrict__ dx, int B, int C, int D) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, d = blockIdx.x * 64 + lane;
+    const float* dyr = dy + (int64_t)b * C;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += dy[(int64_t)b * C + c] * W[(int64_t)c * D + d];
-    dx[i] = s;
+    if (d < D) {
+#pragma unroll 4
+        for (int c = wave; c < C; c += 4) s += dyr[c] * W[(int64_t)c * D + d];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && d < D) dx[(int64_t)b * D + d] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW,
                                      float* __restrict__ db, int accumulate, int B, int C, int D) {
@@ -260,7 +268,7 @@ extern "C" int pa_linear_f32_bwd(const float* dy, const float* x, const float* W
                                  int accumulate, int B, int C, int D, void* stream) {
     if (!dy || !x || !W || !dx || !dW || !db || B <= 0 || C <= 0 || D <= 0) return PA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv((int64_t)B * D, 256)), dim3(256), 0, st, dy, W, dx, B, C, D);
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(D, 64), (unsigned)B), dim3(256), 0, st, dy, W, dx, B, C, D);
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)cdiv((int64_t)C * D + C, 256)), dim3(256), 0, st, dy, x, dW, db, accumulate, B, C, D);

@@ -51,7 +51,8 @@ __global__ void patch_param_grads_kernel(const float* __restrict__ gsum, int D, 
                                          float* __restrict__ d_cls, float* __restrict__ d_dist, float* __restrict__ d_npe,
                                          float* __restrict__ d_bias, float* __restrict__ d_tpos, float* __restrict__ d_fpos,
                                          int accumulate) {
-    // index space: [D bias+prefix] ++ [D*Tpe time] ++ [D*Fpe freq]
+    // index space: [D bias+prefix] ++ [Tpe x D time] ++ [Fpe x D freq], the channel d fastest: every gsum read is a
+    // coalesced row segment and the "does patch p belong to this time / frequency slot" test is wave-uniform
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n0 = D, n1 = (int64_t)D * Tpe, n2 = (int64_t)D * Fpe;
     auto put = [&](float* p, float v) { *p = (accumulate ? *p : 0.f) + v; };
@@ -66,18 +67,18 @@ __global__ void patch_param_grads_kernel(const float* __restrict__ gsum, int D, 
         put(d_npe + D + d, gsum[D + d]);
     } else if (i < n0 + n1) {
         const int64_t k = i - n0;
-        const int d = (int)(k / Tpe), tt = (int)(k % Tpe);
+        const int tt = (int)(k / D), d = (int)(k % D);
         float s = 0.f;
         for (int p = 0; p < Np; ++p)
             if (toff + pt[p] == tt) s += gsum[(int64_t)(2 + p) * D + d];
-        put(d_tpos + k, s);
+        put(d_tpos + (int64_t)d * Tpe + tt, s);
     } else if (i < n0 + n1 + n2) {
         const int64_t k = i - n0 - n1;
-        const int d = (int)(k / Fpe), f = (int)(k % Fpe);
+        const int f = (int)(k / D), d = (int)(k % D);
         float s = 0.f;
         for (int p = 0; p < Np; ++p)
             if (pf[p] == f) s += gsum[(int64_t)(2 + p) * D + d];
-        put(d_fpos + k, s);
+        put(d_fpos + (int64_t)d * Fpe + f, s);
     }
 }
 
