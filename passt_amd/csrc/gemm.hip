@@ -1189,11 +1189,16 @@ __global__ __launch_bounds__(256) void stage_weights_kernel(const pa_stage_desc*
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t n,
-                                       float* __restrict__ out, int accumulate) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+// 16-byte accesses over n4 = n/4 vectors (0 when a pointer or the slab pitch is not 16-byte aligned) + scalar tail
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t n4, int64_t n,
+                                                              float* __restrict__ out, int accumulate) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4; i += stride) {
+        f32x4 s = accumulate ? ((const f32x4*)out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) s += *(const f32x4*)(part + (int64_t)z * n + i * 4);
+        ((f32x4*)out)[i] = s;
+    }
+    for (int64_t i = n4 * 4 + t0; i < n; i += stride) {
         float s = accumulate ? out[i] : 0.f;
         for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
         out[i] = s;
@@ -1313,8 +1318,10 @@ extern "C" int pa_stage_weights(const pa_stage_desc* descs, int n_desc, int tota
 extern "C" int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out,
                                   int accumulate, void* stream) {
     if (!partial || !out || splits < 1 || n <= 0) return PA_EINVAL;
-    const int blocks = (int)std::min<int64_t>(cdiv(n, 256), 4096);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, n, out, accumulate);
+    const bool vec = (((uintptr_t)partial | (uintptr_t)out) & 15) == 0 && n % 4 == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const int blocks = (int)std::min<int64_t>(cdiv(std::max<int64_t>(n4, n - 4 * n4), 256), 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, n4, n, out, accumulate);
     return check_launch();
 }
 

@@ -31,18 +31,31 @@ __global__ void mixup_scalar_kernel(const float* __restrict__ x, const int32_t* 
         o[i] = xa[i] * l + xb[i] * (1.f - l);
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        float pi = p[i] * (1.f - lr * wd);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= (lr / bc1) * (mi / denom);
-        p[i] = pi;
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps,
+                                          float wd, float bc1, float bc2_sqrt) {
+    float pi = p * (1.f - lr * wd);
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = pi - (lr / bc1) * (m / denom);
+}
+// 16-byte accesses (n4 = n / 4 when all four pointers are 16-byte aligned, else 0) + scalar tail
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4; i += stride) {
+        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e], me = mv[e], ve = vv[e];
+            adamw_one(pe, gv[e], me, ve, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
+        }
+        ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
     }
+    for (int64_t i = n4 * 4 + t0; i < n; i += stride) adamw_one(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
 }
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
@@ -126,8 +139,10 @@ extern "C" int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     if (!p || !g || !m || !v || n <= 0 || step < 1) return PA_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    const int blocks = (int)std::min<int64_t>(cdiv(n, 256), 8192);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const int blocks = (int)std::min<int64_t>(cdiv(std::max<int64_t>(n4, 1), 256), 8192);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, sqrtf(bc2));
     return check_launch();
 }
