@@ -157,7 +157,8 @@ typedef struct {
     int32_t tune;          /* 0 = library heuristic (tile quantisation x measured rates).  Forcing a variant
                             * (benchmarking / autotuning), pa_gemm_nt bf16: 1 = 128x128 tile, 4 waves, 2 workgroups/CU;
                             * 2 = 256x256 lockstep; 6 / 7 / 8 = role-split 256x256 / 192x256 / 128x256 (8 waves,
-                            * staggered wave groups).  pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256. */
+                            * staggered wave groups); 9 = 128x256, 4 waves, 64-byte stages, 2 workgroups/CU (slower: DESIGN.md 4.1).
+                            * pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256. */
     /* PA_EPI_DGELU only, optional: colsum_out[n] = (colsum_accumulate ? colsum_out[n] : 0) + sum_m out[m][n] (of the
      * f32 values, before rounding) -- the bias gradient of the Linear whose pre-activation is `aux` (fc1.bias),
      * reduced inside the epilogue instead of by a separate pass over out_lp.  colsum_ws: f32 workspace of

@@ -275,11 +275,21 @@ __device__ __forceinline__ void tile_coords(int pid, int tiles_m, int tiles_n, i
 // Workgroup tile = (WM*TM*32) x (WN*64): WM x WN waves, each owning TM x 2 MFMA 32x32 accumulators
 // (wave tile TM*32 rows x 64 columns); STAGES-deep LDS ring.  Larger wave tiles cut LDS bytes per MFMA
 // (fragments per MFMA: (TM+2)/(2 TM) = 1.0 at TM=2, 0.75 at TM=4).
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+// KBT = K bytes per ring stage: 128 (default) or 64.  With 64-byte rows the XOR term is (row >> 2) & 3: the four rows
+// of a 16-lane ds_read_b128 group that share a 64-byte bank quarter get four different 16-byte slots.  The 64-byte
+// form exists for the 128x256 / 4-wave / 3-stage variant (72 KiB: TWO workgroups per CU, so one workgroup's epilogue
+// overlaps the other's K loop).
+template <int KBT> __device__ __forceinline__ int swz_rows(int row) {
+    if constexpr (KBT == 128) return swz_f128(row);
+    else return (row >> 2) & 3;
+}
+
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(KBT == 64 ? 2 : 1))) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                                const int nwg, const int ksteps_per_split) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
-    constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = TBM * KBT, B_BYTES = TBN * KBT, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int CPR = KBT / 16, NSUB = KBT / 32;       // 16-byte chunks per row, 16-wide k-substeps per stage
     constexpr int NW = WM * WN;
     constexpr int A_PER = (A_BYTES / 1024) / NW;      // A copies per wave per stage
     constexpr int B_PER = (B_BYTES / 1024) / NW;      // B copies per wave per stage
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
     int tm, tn;
     tile_coords(xcd_swizzle(blockIdx.x, nwg), tiles_m, tiles_n, 1024 / TBM, tm, tn);
     const int m0 = tm * TBM, n0 = tn * TBN;
-    const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int ksteps_total = (int)((int64_t)a.K * sizeof(T) / KBT);
     const int ks_begin = blockIdx.y * ksteps_per_split;
     const int ks_end = min(ksteps_total, ks_begin + ksteps_per_split);
     const int nsteps = ks_end - ks_begin;
@@ -306,18 +316,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int q = (wave * A_PER + i) * 64 + lane;
-        const int row = q >> 3;
-        const int c = (q & 7) ^ swz_f128(row);
+        const int row = q / CPR;
+        const int c = (q % CPR) ^ swz_rows<KBT>(row);
         const int gm = min(m0 + row, a.M - 1);
-        srcA[i] = (const char*)a.A + ((int64_t)gm * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        srcA[i] = (const char*)a.A + ((int64_t)gm * a.lda) * sizeof(T) + c * 16 + (int64_t)ks_begin * KBT;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int q = (wave * B_PER + i) * 64 + lane;
-        const int row = q >> 3;
-        const int c = (q & 7) ^ swz_f128(row);
+        const int row = q / CPR;
+        const int c = (q % CPR) ^ swz_rows<KBT>(row);
         const int gn = min(n0 + row, a.N - 1);
-        srcB[i] = (const char*)a.B + ((int64_t)gn * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KB;
+        srcB[i] = (const char*)a.B + ((int64_t)gn * a.ldb) * sizeof(T) + c * 16 + (int64_t)ks_begin * KBT;
     }
     auto stage = [&](int buf, int step) {
         char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
@@ -325,12 +335,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
 #pragma unroll
         for (int i = 0; i < A_PER; ++i)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KB),
+                (const __attribute__((address_space(1))) void*)(srcA[i] + (int64_t)step * KBT),
                 (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KB),
+                (const __attribute__((address_space(1))) void*)(srcB[i] + (int64_t)step * KBT),
                 (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
     };
 
@@ -343,9 +353,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // read offsets: row = base + i*32 + (lane&31); swz_f128(row) == swz_f128(lane) for every i
-    const int rsw = swz_f128(lane);
-    const int offA = (wr * (TM * 32) + (lane & 31)) * 128;
-    const int offB = (wc * 64 + (lane & 31)) * 128;
+    const int rsw = swz_rows<KBT>(lane & 31);
+    const int offA = (wr * (TM * 32) + (lane & 31)) * KBT;
+    const int offB = (wc * 64 + (lane & 31)) * KBT;
     const int half = lane >> 5;
 
     // prologue: fill STAGES-1 ring slots
@@ -373,14 +383,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
         auto read_frags = [&](int slot, int ks) {
             const int coff = ((ks * 2 + half) ^ rsw) << 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * KBT + coff);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[slot][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
+            for (int j = 0; j < 2; ++j) fb[slot][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * KBT + coff);
         };
         read_frags(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) read_frags((ks + 1) & 1, ks + 1);
+        for (int ks = 0; ks < NSUB; ++ks) {
+            if (ks + 1 < NSUB) read_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -392,23 +402,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const pa_gemm_arg
     gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8, tm * WM + wr);
 }
 
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES>
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB>
 static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
-    constexpr int LDS = STAGES * (TBM + TBN) * KB;
+    constexpr int LDS = STAGES * (TBM + TBN) * KBT;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static_assert(LDS >= WM * WN * 32 * 68 * 4, "epilogue slabs must fit");
     const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, TBN);
     const int nwg = tiles_m * tiles_n;
-    const int ksteps = (int)((int64_t)a.K * sizeof(T) / KB);
+    const int ksteps = (int)((int64_t)a.K * sizeof(T) / KBT);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES>,
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
                        tiles_m, tiles_n, nwg, per);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * WM, st);
@@ -685,6 +695,7 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
             case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
             case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
             case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2>(a, st);   // 192x128, 4 waves (96x64 each), 80 KiB: 2 workgroups / CU
+            case 9: return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64>(a, st);   // 128x256, 4 waves (128x64 each), 3 x 24 KiB stages: 2 workgroups / CU
             case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
             case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
             case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split

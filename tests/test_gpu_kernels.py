@@ -60,7 +60,7 @@ def test_gemm_store_bias(dt, M, N, K):
     assert e < tol(dt), e
 
 
-@pytest.mark.parametrize("tune", [0, 1, 2, 3, 6, 7, 8])
+@pytest.mark.parametrize("tune", [0, 1, 2, 3, 6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (300, 264, 128), (2 * 474, 2304, 256)])
 def test_gemm_tile_variants(tune, M, N, K):
     """every workgroup-tile / pipeline variant of pa_gemm_nt (pa_gemm_args.tune) computes the same GEMM"""
