@@ -182,7 +182,7 @@ def main():
             achieved = tot_flop / tot_ms / 1e9
             # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
             # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
-            # over this very command and committed (tools_gemm_traffic.py -> profiles/r01_gemm_traffic.json)
+            # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
             if os.path.isfile(tpath) and args.batch == 64 and args.precision == "bf16":

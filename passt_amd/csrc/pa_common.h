@@ -76,7 +76,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // ---- GELU for the bf16 epilogues: odd minimax polynomials on the clamped argument, two elements per
 // v_pk_fma_f32 and no transcendental (quarter-rate) instruction.  The fc1 / dgrad-fc2 GEMM epilogues are VALU
 // bound (65536 outputs per CU per tile), so this is ~2.7x cheaper than the erf form above.  Coefficients and
-// error bounds from tools_gelu_fit.py: |Phi err| <= 1.3e-5, |gelu' err| <= 1.5e-4 in f32 evaluation -- 1/30 and
+// error bounds from tools/gelu_fit.py: |Phi err| <= 1.3e-5, |gelu' err| <= 1.5e-4 in f32 evaluation -- 1/30 and
 // 1/10 of a bf16 half-ulp of the stored results.  The f32 parity path keeps gelu_erf / gelu_erf_grad.
 //   Phi(x)   = 1/2 + xc P(xc^2),   gelu'(x) = 1/2 + xc Q(xc^2),   xc = clamp(x, -4.25, 4.25)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

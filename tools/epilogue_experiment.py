@@ -3,7 +3,7 @@
 60 / 252 / 504 / 1428 tiles and K = 64 / 768 / 3072; a per-CU-bound epilogue costs the same with 60 tiles as with 252."""
 import json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from passt_amd import ops
 from passt_amd._lib import EPI_DGELU, EPI_GELU, EPI_RESID, EPI_STORE, PA_BF16
 from bench_kernels import timeit

@@ -3,7 +3,7 @@
 (so the per-CU rounds of the two launches drift apart) hide the epilogue write bursts?"""
 import sys, os, json
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from passt_amd import ops
 from passt_amd._lib import EPI_DGELU, EPI_GELU, EPI_RESID, EPI_STORE, PA_BF16
 
