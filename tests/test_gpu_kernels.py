@@ -504,3 +504,44 @@ def test_wave_augment_matches_reference_pipeline():
     wave, _ = aug(x.to(DEV), None, torch.tensor([len(r) for r in raws], dtype=torch.int32), p)
     ref, _ = W.augment_batch(raws, list(p[0]), list(p[1]), list(p[2]), list(p[3]), 320000)
     assert float((wave[:, 0].cpu() - torch.from_numpy(ref)).abs().max()) < 5e-7
+
+
+@pytest.mark.parametrize("tune", [0, 6, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(1, 8, 64), (33, 40, 64), (255, 256, 64), (257, 264, 128), (5000, 8, 192),
+                                   (70000, 264, 64), (3 * 474, 2304, 768)])
+def test_persistent_gemm_edge_shapes(tune, M, N, K):
+    """The persistent role-split kernel at its edges: a single (ragged) tile, one K step, fewer tiles than CUs,
+    hundreds of rounds per workgroup (M = 70000: 274+ row tiles x 2 column tiles), partial tiles on both axes;
+    every epilogue, including split-K partial slabs with an uneven number of K steps per slice."""
+    dt = PA_BF16
+    A = rnd(M, K, seed=80).to(TD[dt]).to(DEV)
+    Bm = rnd(N, K, seed=81, scale=0.5).to(TD[dt]).to(DEV)
+    bias = rnd(N, seed=82).to(DEV)
+    resid = rnd(M, N, seed=83).to(DEV)
+    aux = rnd(M, N, seed=84, scale=2.0).to(TD[dt]).to(DEV)
+    acc = A.double().cpu() @ Bm.double().cpu().T
+    ref = acc + bias.double().cpu()
+    old = ops.GEMM_TUNE
+    try:
+        ops.GEMM_TUNE = tune
+        out = torch.full((M, N), 9.0, device=DEV, dtype=TD[dt])
+        ops.gemm_nt(A, Bm, dt, EPI_STORE, bias=bias, out_lp=out)
+        assert rel_err(out, ref) < tol(dt)
+        pre, act = torch.empty_like(out), torch.empty_like(out)
+        ops.gemm_nt(A, Bm, dt, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
+        assert rel_err(pre, ref) < tol(dt) and rel_err(act, torch.nn.functional.gelu(pre.double().cpu())) < 6e-3
+        out32 = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(A, Bm, dt, EPI_RESID, bias=bias, resid=resid, out_f32=out32)
+        assert rel_err(out32, ref + resid.double().cpu()) < 3e-3
+        dg = torch.empty_like(out)
+        ops.gemm_nt(A, Bm, dt, EPI_DGELU, aux=aux, out_lp=dg)
+        a64 = aux.double().cpu()
+        gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+        assert rel_err(dg, acc * gp) < 1.2e-2
+        ksteps = K * 2 // 128
+        for split in sorted({1, min(2, ksteps), min(3, ksteps)}):
+            part = torch.full((split, M, N), 5.0, device=DEV)
+            ops.gemm_nt(A, Bm, dt, EPI_PARTIAL, out_f32=part, split_k=split)
+            assert rel_err(part.sum(0), acc) < 3e-3, split
+    finally:
+        ops.GEMM_TUNE = old
