@@ -17,6 +17,17 @@
 
 namespace pa {
 
+// occupancy targets of the bf16 kernels (waves per SIMD); overridable for A/B builds
+#ifndef PA_ATTN_FWD_WAVES
+#define PA_ATTN_FWD_WAVES 4
+#endif
+#ifndef PA_ATTN_DQ_WAVES
+#define PA_ATTN_DQ_WAVES 3
+#endif
+#ifndef PA_ATTN_DKDV_WAVES
+#define PA_ATTN_DKDV_WAVES 2
+#endif
+
 static constexpr int HD = 64;       // head dim (all PaSST archs: 768/12, 1024/16, 384/6, 128/2)
 static constexpr int TROWS = 64;    // streamed rows per LDS tile
 static constexpr float LOG2E = 1.4426950408889634f;
@@ -76,12 +87,15 @@ __device__ __forceinline__ typename Frag<T>::type col_frag(const char* lds, int 
 template <>
 __device__ __forceinline__ bf16x8 col_frag<bf16>(const char* lds, int rbase, int s, int d0, int lane) {
     const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
-    const int r1 = rbase + 16 * s + 4 * h + (p >> 2);
+    const int r1 = 4 * h + (p >> 2);                           // row inside the 16-row group
     const int d = d0 + g * 16 + (p & 3) * 4;                   // first of this lane's 4 source elements
     const int within = (d & 7) * 2;
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    const bf16x4 lo = lds_tr16_asm<0>(base + swz128(r1, d >> 3) + within);
-    const bf16x4 hi = lds_tr16_asm<0>(base + swz128(r1 + 8, d >> 3) + within);
+    // the swizzle only looks at row bits 1..3, so the (rbase + 16 s) rows are a pure byte offset: it rides in the
+    // instruction's immediate and the two per-lane addresses are loop invariant up to the tile base
+    const int row_off = (rbase + 16 * s) * 128;
+    const bf16x4 lo = lds_tr16_asm_imm(base + swz128(r1, d >> 3) + within, row_off);
+    const bf16x4 hi = lds_tr16_asm_imm(base + swz128(r1 + 8, d >> 3) + within, row_off);
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -136,7 +150,7 @@ static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
 // forward
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 4 : 2))) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_FWD_WAVES : 2))) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
                                                        int ldo, float* __restrict__ lse, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 // backward, part 1: dK, dV.  Workgroup owns 128 keys (lane = key); queries stream through LDS.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DKDV_WAVES : 1))) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ d_o, int ldo,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const T* __restrict_
 // backward, part 2: dQ.  Workgroup owns 128 queries (lane = query); keys stream through LDS.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DQ_WAVES : 1))) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {

@@ -98,5 +98,12 @@ __device__ __forceinline__ bf16x4 lds_tr16_asm(uint32_t lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
     return __builtin_bit_cast(bf16x4, r);
 }
+// same, the immediate given as an argument that must fold to a constant after inlining / unrolling
+__device__ __forceinline__ bf16x4 lds_tr16_asm_imm(uint32_t lds_addr, int off) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(off));
+    return __builtin_bit_cast(bf16x4, r);
+}
 
 }  // namespace pa
