@@ -18,6 +18,11 @@
 namespace pa {
 
 // occupancy targets of the bf16 kernels (waves per SIMD); overridable for A/B builds
+// 1 = packed f32 math (v_pk_fma_f32 ...) around the exponentials.  Measured slower than scalar (bwd 239 vs 234 us, run
+// 60): the register-pair constraint costs ~30 v_mov per tile and packed VALU issues badly next to MFMAs.
+#ifndef PA_ATTN_PK
+#define PA_ATTN_PK 0
+#endif
 #ifndef PA_ATTN_FWD_WAVES
 #define PA_ATTN_FWD_WAVES 4
 #endif
@@ -34,7 +39,7 @@ static constexpr float LOG2E = 1.4426950408889634f;
 static constexpr float LN2 = 0.6931471805599453f;
 
 // The softmax / dS element loops are VALU bound (the exponential is a quarter-rate instruction and there is one
-// per score), so everything around it is done two scores per instruction (v_pk_fma_f32 / v_pk_mul_f32).
+// per score).  Two-scores-per-instruction forms (PA_ATTN_PK) are kept for reference only.
 __device__ __forceinline__ f32x2 exp2_2(f32x2 a) { return f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])}; }
 
 template <typename T> struct Tile {
@@ -214,6 +219,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc * sl2);         // running max in log2 units (sl2 > 0)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#if !PA_ATTN_PK
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sl2, -m_new));
+                s[kb][r] = p;
+                psum += p;
+            }
+#else
         f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -225,6 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 ps2 += p;
             }
         float psum = ps2[0] + ps2[1];
+#endif
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -332,6 +349,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 mma32<T>(dpa, row_frag<T>(sDO, qb * 32 + (lane & 31), st, lane), vf[st]);
             }
 #pragma unroll
+#if !PA_ATTN_PK
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qb * 32 + acc_row(r, lane);
+                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -sLse[ql] * LOG2E));
+                sa[r] = p;
+                dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;
+            }
+#else
             for (int r = 0; r < 16; r += 2) {                   // rows r, r+1 of the accumulator are consecutive queries
                 const int ql = qb * 32 + acc_row(r, lane);
                 const f32x2 l2 = f32x2{sLse[ql], sLse[ql + 1]} * pk_splat(-LOG2E);
@@ -340,6 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 sa[r] = p[0]; sa[r + 1] = p[1];               // P
                 dpa[r] = ds[0]; dpa[r + 1] = ds[1];           // dS
             }
+#endif
             // queries beyond nq exist only in the last tile (uniform branch); lanes whose own key is beyond
             // N only produce their own, never stored, outputs and need no mask
             if (qt == ntiles - 1 && (nq & (TROWS - 1))) {
@@ -460,11 +486,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 mma32<T>(dpa, row_frag<T>(sV, kb * 32 + (lane & 31), st, lane), dof[st]);
             }
 #pragma unroll
+#if !PA_ATTN_PK
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -lse2));
+                dpa[r] = p * fmaf(dpa[r], scale, -dlt * scale);
+            }
+#else
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 p = exp2_2(pk_fma(f32x2{sa[r], sa[r + 1]}, pk_splat(sl2), pk_splat(-lse2)));
                 const f32x2 ds = p * pk_fma(f32x2{dpa[r], dpa[r + 1]}, pk_splat(scale), pk_splat(-dlt * scale));   // dS^T
                 dpa[r] = ds[0]; dpa[r + 1] = ds[1];
             }
+#endif
             if (kt == ntiles - 1 && (N & (TROWS - 1))) {       // keys beyond N: last tile only
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
