@@ -17,6 +17,9 @@
 
 namespace pa {
 
+#ifndef PA_NT_SUBSTEPS
+#define PA_NT_SUBSTEPS 1
+#endif
 static constexpr int BM = 128, BN = 128, KB = 128;  // KB: K bytes per step
 static constexpr int TILE_BYTES = BM * KB;            // 16 KiB per operand tile
 static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
@@ -574,31 +577,38 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             // the K-tile fetched during this one: t+1 of this item, or tile 0 of the next item
             if (last && have_next) point_at(round + 1, m0, n0, split);
             const int dstep = last ? 0 : t + 1;
+            // PA_NT_SUBSTEPS 16-wide k-substeps per L / M segment pair (1: 8 barriers per K-tile, 2: 4)
+            constexpr int SUB = PA_NT_SUBSTEPS, NPH = 4 / SUB;
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph) {
+            for (int ph = 0; ph < NPH; ++ph) {
                 // ---------------- L segment ----------------
-                typename Frag<T>::type fa[TM], fb[2];
-                const int coff = ((ph * 2 + half) ^ rsw) << 4;
+                typename Frag<T>::type fa[SUB][TM], fb[SUB][2];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+                for (int u = 0; u < SUB; ++u) {
+                    const int coff = (((ph * SUB + u) * 2 + half) ^ rsw) << 4;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
-                if (more) {
-                    if (ph == 0) dmaA(gbuf ^ 1, dstep);
-                    if (ph == 1) dmaB(gbuf ^ 1, dstep);
+                    for (int i = 0; i < TM; ++i) fa[u][i] = *(const typename Frag<T>::type*)(sA + offA + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[u][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
                 }
-                if (ph == 3 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more) {      // the whole next K-tile is requested at least one full segment pair before it is waited for
+                    if (ph == 0) dmaA(gbuf ^ 1, dstep);
+                    if (ph == (NPH == 4 ? 1 : 0)) dmaB(gbuf ^ 1, dstep);
+                }
+                if (ph == NPH - 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M segment ----------------
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int u = 0; u < SUB; ++u)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[i], fb[j]);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
                 __builtin_amdgcn_s_setprio(0);
-                if (ph == 3 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (ph == NPH - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
