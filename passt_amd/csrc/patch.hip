@@ -58,8 +58,13 @@ __global__ void patch_param_grads_kernel(const float* __restrict__ gsum, int D, 
     auto put = [&](float* p, float v) { *p = (accumulate ? *p : 0.f) + v; };
     if (i < n0) {
         const int d = (int)i;
-        float s = 0.f;
-        for (int p = 0; p < Np; ++p) s += gsum[(int64_t)(2 + p) * D + d];
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent chains: the loop is load-latency bound
+        int p = 0;
+        for (; p + 8 <= Np; p += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += gsum[(int64_t)(2 + p + u) * D + d];
+        for (; p < Np; ++p) s8[0] += gsum[(int64_t)(2 + p) * D + d];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         put(d_bias + d, s);
         put(d_cls + d, gsum[d]);
         put(d_dist + d, gsum[D + d]);
