@@ -21,6 +21,7 @@ Besides the contract line it reports
                  host on a bounded sample of the same workload (train-mode fwd+bwd, B=4 per iteration).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -108,7 +109,8 @@ def main():
 
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
-    with warnings.catch_warnings():
+    # module construction prints the reference's notices ("Warning: FMAX is None ..."): keep stdout for the ONE JSON line
+    with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
         warnings.simplefilter("ignore")
         net = passt_amd.get_model(arch=ARCH, pretrained=False, s_patchout_t=40, s_patchout_f=4).to(dev).train()
         mel = None if args.no_mel else passt_amd.AugmentMelSTFT(
