@@ -39,6 +39,9 @@ ARCH = "passt_s_swa_p16_128_ap476"
 CLIP_SAMPLES = 320000                # 10 s @ 32 kHz
 
 
+PROFILE_EVERY = 5      # timed steps between two steps that carry per-launch HIP events
+
+
 def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
     """per block 24 N D^2 + 4 N^2 D, patch embed 2 P 256 D (kept patches only),
     fwd+bwd = 3x fwd."""
@@ -83,6 +86,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events (measures their cost)")
     ap.add_argument("--no-mel", action="store_true", help="feed spectrograms (reference model_speed_test style)")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sgd"])
     ap.add_argument("--overlap-wgrad", action="store_true",
@@ -139,14 +143,16 @@ def main():
         for _ in range(args.warmup):
             ts.step(x, y)
         barrier()
-        ops.GEMM_PROFILE = {} if rank == 0 else None
+        # per-launch HIP events on the GEMM family (roofline): two event records per launch cost ~3.4 % of the step
+        # when every step is instrumented, so one timed step in PROFILE_EVERY carries them (always including step 0)
+        prof = {} if (rank == 0 and not args.no_roofline) else None
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            ops.GEMM_PROFILE = prof if (prof is not None and i % PROFILE_EVERY == 0) else None
             loss = ts.step(x, y)
+        ops.GEMM_PROFILE = None
         barrier()
         t1 = time.perf_counter()
-    prof = ops.GEMM_PROFILE
-    ops.GEMM_PROFILE = None
     elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -198,6 +204,7 @@ def main():
                                "kernel": "GEMM family pa::gemm_nt_stagger_kernel / gemm_nt_kernel / gemm_tn_stagger_kernel <bf16> "
                                          "(all epilogues + weight gradients; 2*M*N*K algorithmic FLOPs per launch)",
                                "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
+                               "sampling": f"HIP events around every GEMM launch of 1 timed step in {PROFILE_EVERY} (steps 0, {PROFILE_EVERY}, ...)",
                                "gemm_time_share_of_step": round(tot_ms / (1e3 * elapsed), 3),
                                "per_epilogue": per_kind}
         if world == 1 and not args.no_cpu_baseline:
