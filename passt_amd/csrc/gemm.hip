@@ -1418,8 +1418,25 @@ extern "C" int pa_scatter_rows(const void* in, const int32_t* idx, int n_idx, in
     return check_launch();
 }
 
+namespace pa {
+// strided zero fill with 16-byte stores (hipMemset2DAsync's fill kernel ran at 0.7 TB/s on the [M][768] bf16 third of dqkv)
+__global__ __launch_bounds__(256) void zero2d_kernel(char* __restrict__ p, int64_t pitch, int64_t w16, int64_t rows) {
+    const int64_t n = rows * w16, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / w16, c = i - r * w16;
+        *(f32x4*)(p + r * pitch + c * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+}  // namespace pa
+
 extern "C" int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, int64_t rows, void* stream) {
     if (!ptr || pitch_bytes < width_bytes || width_bytes <= 0 || rows <= 0) return PA_EINVAL;
+    if (pitch_bytes != width_bytes && ((uintptr_t)ptr | pitch_bytes | width_bytes) % 16 == 0) {
+        const int64_t w16 = width_bytes / 16;
+        const int blocks = (int)std::min<int64_t>(cdiv(rows * w16, 256), 8192);
+        hipLaunchKernelGGL(zero2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (char*)ptr, pitch_bytes, w16, rows);
+        return check_launch();
+    }
     hipError_t e = pitch_bytes == width_bytes
                        ? hipMemsetAsync(ptr, 0, (size_t)(width_bytes * rows), (hipStream_t)stream)
                        : hipMemset2DAsync(ptr, (size_t)pitch_bytes, 0, (size_t)width_bytes, (size_t)rows, (hipStream_t)stream);

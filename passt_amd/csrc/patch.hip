@@ -87,12 +87,25 @@ __global__ void patch_param_grads_kernel(const float* __restrict__ gsum, int D, 
     }
 }
 
-// dpatch[(b*Np+p)][d] = dtok[b][2+p][d]
+// dpatch[(b*Np+p)][d] = dtok[b][2+p][d]; 8 elements per thread (D % 8 == 0 fast path: two 16-byte loads, one 16-byte
+// bf16 store, one row decomposition per vector), scalar otherwise
 template <typename T>
 __global__ void patch_rows_kernel(const float* __restrict__ dtok, int Ntok, int D, int Np, T* __restrict__ dpatch, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+    if ((D & 7) == 0) {
+        const int dv = D >> 3;
+        const int64_t nv = n >> 3;
+        for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+            const int64_t row = v / dv;
+            const int d = (int)(v - row * dv) * 8;
+            const int64_t b = row / Np, p = row - b * Np;
+            float x[8];
+            load8<float>(dtok + (b * Ntok + 2 + p) * D + d, x);
+            store8<T>(dpatch + row * D + d, x);
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t row = i / D;
         const int d = (int)(i % D);
         const int64_t b = row / Np, p = row % Np;
