@@ -49,7 +49,7 @@ def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
     return 3 * fwd / 1e9
 
 
-def cpu_baseline(budget_s=20.0, threads=None):
+def cpu_baseline(budget_s=12.0, threads=None):
     """Oracle (port of the reference) fwd+bwd in train mode on this host's cores.  Bounded: at most
     ~budget_s of CPU work; the thread count is capped (torch's CPU GEMMs stop scaling -- and collapse from
     oversubscription -- long before the 100+ hardware threads of a GPU host)."""
@@ -69,7 +69,7 @@ def cpu_baseline(budget_s=20.0, threads=None):
         lo, _ = O.passt_forward(sd, x, cfg, training=True)
         O.bce_loss(lo, y).backward()
         times.append(time.time() - t0)
-        if time.time() - t_start > budget_s or len(times) >= 12:
+        if time.time() - t_start > budget_s or len(times) >= 40:
             break
     used = times[1:] if len(times) > 1 else times          # drop the warm-up iteration when there is another
     dt = sum(used)
