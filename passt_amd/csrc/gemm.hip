@@ -17,6 +17,9 @@
 
 namespace pa {
 
+#ifndef PA_NT_GROUP_M
+#define PA_NT_GROUP_M 4      // row-tiles walked per column-tile by consecutive work items (L2 patch shape)
+#endif
 #ifndef PA_NT_SUBSTEPS
 #define PA_NT_SUBSTEPS 1
 #endif
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         const int item = r * nres + xcd_swizzle(bid, n);
         int tm, tn;
         const int sp = item / nwg;
-        tile_coords(item - sp * nwg, tiles_m, tiles_n, 4, tm, tn);
+        tile_coords(item - sp * nwg, tiles_m, tiles_n, PA_NT_GROUP_M, tm, tn);
         tab[r] = make_int4(tm * TBM, tn * TBN, sp, 0);
     }
     __syncthreads();
