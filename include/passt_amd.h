@@ -174,6 +174,12 @@ int pa_gemm_nt(const pa_gemm_args* a, void* stream);
  * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over
  * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic). */
 int pa_gemm_tn(const pa_gemm_args* a, void* stream);
+/* Up to PA_TN_BATCH_MAX bf16 weight-gradient problems in ONE launch (e.g. the four Linears of a transformer block,
+ * once all their operands exist): the work items of all problems share one grid, so there is no drain / prologue
+ * between problems and items of different length pack onto the CUs.  Same arguments and results as n calls of
+ * pa_gemm_tn; `a` is a HOST array. */
+#define PA_TN_BATCH_MAX 4
+int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream);
 /* Row gather / scatter and strided zero fill (prefix-token path of the last block):
  * gather: out[i] = in[idx[i]]; scatter: out[idx[i]] = in[i]; rows of row_bytes bytes (multiple of 4). */
 int pa_gather_rows(const void* in, const int32_t* idx, int n_idx, int64_t row_bytes, void* out, void* stream);
@@ -183,6 +189,16 @@ int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, int64_t rows,
 /* out[i] = (accumulate ? out[i] : 0) + sum_z partial[z][i], i < n */
 int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out, int accumulate,
                        void* stream);
+/* the same for up to PA_REDUCE_BATCH_MAX slab sets in one launch (`d` is a HOST array) */
+#define PA_REDUCE_BATCH_MAX 8
+typedef struct pa_reduce_desc {
+    const float* partial;
+    float* out;
+    int64_t n;
+    int32_t splits;
+    int32_t accumulate;
+} pa_reduce_desc;
+int pa_reduce_partials_batched(const pa_reduce_desc* d, int n, void* stream);
 /* out[r] = (accumulate ? out[r] : 0) + sum_c in[r][c], c < C  (bias gradients from dY^T) */
 int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate,
               void* stream);

@@ -33,6 +33,10 @@ class GemmArgs(C.Structure):
                 ("colsum_out", vp), ("colsum_ws", vp), ("colsum_accumulate", i32), ("reserved", i32)]
 
 
+class ReduceDesc(C.Structure):         # == pa_reduce_desc
+    _fields_ = [("partial", vp), ("out", vp), ("n", i64), ("splits", i32), ("accumulate", i32)]
+
+
 class StageDesc(C.Structure):          # == pa_stage_desc
     _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("rows", i32), ("cols", i32), ("tile_begin", i32), ("reserved", i32)]
 
@@ -53,6 +57,8 @@ SIGNATURES = {
     "pa_gemm_colsum_ws_floats": (i64, [i32, i32]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
+    "pa_gemm_tn_batched": (i32, [C.POINTER(GemmArgs), i32, vp]),
+    "pa_reduce_partials_batched": (i32, [C.POINTER(ReduceDesc), i32, vp]),
     "pa_colsum_ws_floats": (i64, [i32, i32]),
     "pa_colsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp]),
     "pa_reduce_partials": (i32, [vp, i32, i64, vp, i32, vp]),

@@ -886,8 +886,9 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int ms, int cbase, 
     return f;
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
-                                                              const int steps_per_split) {
+// one work item: output tile `tile_id` (already XCD-remapped) of problem `a`, K slice `split`
+__device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int split,
+                                                     const int steps_per_split) {
     constexpr int TM = 4, WN = 4, MROWS = 64;
     constexpr int OP_BYTES = MROWS * 512, STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -895,11 +896,11 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    const int bid = xcd_swizzle(blockIdx.x, nwg);
+    const int bid = tile_id;
     const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;     // dY columns / X columns of this tile
     const int Mtok = a.K;
     const int steps_total = (Mtok + MROWS - 1) / MROWS;
-    const int st_begin = blockIdx.y * steps_per_split;
+    const int st_begin = split * steps_per_split;
     const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
 
     // this wave's 4 + 4 LDS-DMA pieces per stage: piece q = wave*4+i covers tile rows 2q, 2q+1 (512 B each).
@@ -1039,7 +1040,29 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args
         phase(std::integral_constant<int, 3>{});
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, blockIdx.y, wr, wc, lane);
+    gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, split, wr, wc, lane);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
+                                                              const int steps_per_split) {
+    gemm_tn_stagger_item(a, tiles_n, xcd_swizzle(blockIdx.x, nwg), blockIdx.y, steps_per_split);
+}
+
+// Several weight-gradient problems in one launch (pa_gemm_tn_batched): workgroup -> (problem, tile, K slice).  The
+// hardware hands work items to CUs as they free up, so problems of different length pack without a launch boundary
+// (drain + prologue) between them.
+struct TnBatch {
+    pa_gemm_args a[PA_TN_BATCH_MAX];
+    int32_t first[PA_TN_BATCH_MAX + 1];      // first work item of problem p; first[n] = total
+    int32_t tiles_n[PA_TN_BATCH_MAX], nwg[PA_TN_BATCH_MAX], per[PA_TN_BATCH_MAX];
+    int32_t n;
+};
+__global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBatch b) {
+    int p = 0;
+    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    const int item = blockIdx.x - b.first[p];
+    const int split = item / b.nwg[p], t = item - split * b.nwg[p];
+    gemm_tn_stagger_item(b.a[p], b.tiles_n[p], xcd_swizzle(t, b.nwg[p]), split, b.per[p]);
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
@@ -1385,6 +1408,73 @@ extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     if (a->dtype == PA_BF16) return a->tune == 1 ? launch_gemm_tn<bf16>(*a, st) : launch_gemm_tn_stagger(*a, st);
     if (a->dtype == PA_F32) return launch_gemm_tn<float>(*a, st);
     return PA_EINVAL;
+}
+
+extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
+    if (!a || n < 1 || n > PA_TN_BATCH_MAX) return PA_EINVAL;
+    TnBatch batch;
+    TnBatch* pb = &batch;
+    int total = 0;
+    for (int p = 0; p < n; ++p) {
+        const pa_gemm_args& x = a[p];
+        if (!x.A || !x.B || !x.out_f32 || x.M <= 0 || x.N <= 0 || x.K <= 0 || x.split_k < 1) return PA_EINVAL;
+        if (x.dtype != PA_BF16 || x.epilogue != PA_EPI_PARTIAL) return PA_EUNSUPPORTED;
+        if ((x.lda * 2) % 16 || (x.ldb * 2) % 16 || x.ldo32 % 4 || x.M < 8 || x.N < 8 || x.N % 8 || x.M % 8) return PA_EUNSUPPORTED;
+        pb->a[p] = x;
+        pb->tiles_n[p] = (int)cdiv(x.N, 256);
+        pb->nwg[p] = (int)cdiv(x.M, 256) * pb->tiles_n[p];
+        pb->per[p] = (int)cdiv(cdiv(x.K, 64), x.split_k);
+        pb->first[p] = total;
+        total += pb->nwg[p] * x.split_k;
+    }
+    pb->first[n] = total;
+    pb->n = n;
+    constexpr int LDS = 2 * 2 * 64 * 512;
+    static bool attr_set = [] {
+        return hipFuncSetAttribute((const void*)gemm_tn_stagger_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS) == hipSuccess;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL(gemm_tn_stagger_batched_kernel, dim3(total), dim3(512), LDS, (hipStream_t)stream, batch);
+    return check_launch();
+}
+
+namespace pa {
+struct ReduceBatch {
+    pa_reduce_desc d[PA_REDUCE_BATCH_MAX];
+    int32_t n;
+};
+// blockIdx.y = problem; same arithmetic (and summation order) as reduce_partials_kernel
+__global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const ReduceBatch b) {
+    const pa_reduce_desc& d = b.d[blockIdx.y];
+    const int64_t n = d.n, n4 = (n % 4 == 0 && (((uintptr_t)d.partial | (uintptr_t)d.out) & 15) == 0) ? n / 4 : 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4; i += stride) {
+        f32x4 s = d.accumulate ? ((const f32x4*)d.out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < d.splits; ++z) s += *(const f32x4*)(d.partial + (int64_t)z * n + i * 4);
+        ((f32x4*)d.out)[i] = s;
+    }
+    for (int64_t i = n4 * 4 + t0; i < n; i += stride) {
+        float s = d.accumulate ? d.out[i] : 0.f;
+        for (int z = 0; z < d.splits; ++z) s += d.partial[(int64_t)z * n + i];
+        d.out[i] = s;
+    }
+}
+}  // namespace pa
+
+extern "C" int pa_reduce_partials_batched(const pa_reduce_desc* d, int n, void* stream) {
+    if (!d || n < 1 || n > PA_REDUCE_BATCH_MAX) return PA_EINVAL;
+    ReduceBatch b;
+    int64_t nmax = 0;
+    for (int p = 0; p < n; ++p) {
+        if (!d[p].partial || !d[p].out || d[p].splits < 1 || d[p].n <= 0) return PA_EINVAL;
+        b.d[p] = d[p];
+        nmax = std::max<int64_t>(nmax, d[p].n);
+    }
+    b.n = n;
+    const int blocks = (int)std::min<int64_t>(cdiv(cdiv(nmax, 4), 256), 2048);
+    hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, b);
+    return check_launch();
 }
 
 extern "C" int64_t pa_colsum_ws_floats(int R, int C) { return (int64_t)std::min<int64_t>(32, cdiv(R, 256)) * C; }

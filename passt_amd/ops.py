@@ -5,6 +5,7 @@ libpasst_amd.so and returns the output tensors it allocated (torch is the alloca
 No fallback: a non-CUDA tensor or a missing library raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -225,6 +226,23 @@ def pick_split_k_slots(tiles, steps, slots=256):
     return best
 
 
+def pick_batched_splits(probs, slots=256):
+    """probs: [(tiles, k_steps)] of the problems sharing one launch.  Every work item is one 256x256 tile x one K slice of
+    L steps (S_p = ceil(steps_p / L)).  Cost model (us, MI355X measurements): rounds x (L + 3) x 1.6 for the K loops and
+    per-item epilogues, with rounds = ceil(#items / slots), plus 0.05 per item for the f32 partial slab it writes and the
+    reduction reads back (256 KiB each way; about half of it hides under the K loops -- calibrated on the passt_s block:
+    7 slices beat 2 and 4, run 82)."""
+    best, best_cost = None, None
+    for L in range(max(p[1] for p in probs), 3, -1):
+        S = [max(1, min(64, -(-st // L))) for _, st in probs]
+        items = sum(t * s_ for (t, _), s_ in zip(probs, S))
+        per = max(-(-st // s_) for (_, st), s_ in zip(probs, S))
+        cost = -(-items // slots) * (per + 3) * 1.6 + items * 0.05
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = S, cost
+    return best if best is not None else [1] * len(probs)
+
+
 def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     """out[N][K] (+)= dY[M][N]^T X[M][K], operands read in place (pa_gemm_tn), deterministic split-K."""
     Mtok, N = dY.shape
@@ -258,6 +276,46 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
         ev1.record()
         GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, 2.0 * N * K * Mtok))
     check(lib.pa_reduce_partials(_p(part), S, N * K, _p(out_f32), int(accumulate), _stream()), "pa_reduce_partials")
+    return partial_ws
+
+
+def wgrad_tn_batched(problems, dtype, partial_ws=None):
+    """problems: up to 4 of (dY [M][N], X [M][K], out [N][K] f32, accumulate): all weight gradients of a block in ONE
+    pa_gemm_tn_batched launch + ONE batched split-K reduction.  Returns the (possibly grown) partial workspace."""
+    from ._lib import ReduceDesc
+    assert dtype == PA_BF16 and 1 <= len(problems) <= 4
+    metas = []
+    for dY, X, out, acc in problems:
+        Mtok, N = dY.shape
+        metas.append((Mtok, N, X.shape[1]))
+    splits = pick_batched_splits([(((N + 255) // 256) * ((K + 255) // 256), (Mtok + 63) // 64) for Mtok, N, K in metas])
+    need = sum(S * m[1] * m[2] for S, m in zip(splits, metas))
+    if partial_ws is None or partial_ws.numel() < need:
+        partial_ws = torch.empty(need, device=problems[0][0].device, dtype=torch.float32)
+    args = (GemmArgs * len(problems))()
+    red = (ReduceDesc * len(problems))()
+    off, flops = 0, 0.0
+    for a, r, (dY, X, out, acc), (Mtok, N, K), S in zip(args, red, problems, metas, splits):
+        part = partial_ws[off:off + S * N * K]
+        off += S * N * K
+        a.dtype, a.epilogue = dtype, EPI_PARTIAL
+        a.M, a.N, a.K = N, K, Mtok
+        a.lda, a.ldb = dY.stride(0), X.stride(0)
+        a.A, a.B = _p(dY), _p(X)
+        a.out_f32, a.ldo32 = _p(part), K
+        a.split_k, a.tune = S, 0
+        r.partial, r.out, r.n, r.splits, r.accumulate = _p(part), _p(out), N * K, S, int(acc)
+        flops += 2.0 * N * K * Mtok
+    lib = _lib.load()
+    if GEMM_PROFILE is None:
+        check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
+    else:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
+        ev1.record()
+        GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, flops))
+    check(lib.pa_reduce_partials_batched(red, len(problems), _stream()), "pa_reduce_partials_batched")
     return partial_ws
 
 

@@ -351,6 +351,22 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
             if done is not None and on_block_done:
                 on_block_done(done)
 
+    # bf16, single stream: the four weight gradients of a block wait until the block's last operand exists and go out as
+    # ONE batched launch (+ one batched split-K reduction): no drain / prologue between them, equal-sized work items
+    pending = [] if (dt == PA_BF16 and not side.enabled and not os.environ.get("PASST_AMD_NO_BATCH_WGRAD")) else None
+
+    def wgrad(dY, X, dW, db, done=None):
+        if pending is None:
+            return wgrad_async(dY, X, dW, db, done)
+        pending.append((dY, X, dW.view(dY.shape[1], -1), False))
+        if db is not None:
+            ops.colsum(dY, db)
+        if done is not None:
+            scratch["part"] = ops.wgrad_tn_batched(pending, dt, scratch.get("part"))
+            pending.clear()
+            if on_block_done:
+                on_block_done(done)
+
     # head: logits = hn W^T + b ; hn = LN_1e-5(feat) ; feat = mean of the two normed prefix tokens
     dhn = ops.linear_f32_bwd(dlogits.contiguous(), ctx["hn"], model.head[1].weight, g["head.1.weight"],
                              g["head.1.bias"])
@@ -372,20 +388,20 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         # ---- MLP:  x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))      (on [2B, D] rows for the last block)
         # fc2.bias gradient = column sums of dx: already produced by the LayerNorm backward that made dx (the next
         # block's norm1) -- except for the last block, whose dx comes from the head
-        wgrad_async(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"] if last else None)
+        wgrad(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"] if last else None)
         d_pre = torch.empty_like(h_pre)
         # the fc1.bias gradient (column sums of d_pre) comes out of the same epilogue
         cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(d_pre.shape[0], d_pre.shape[1], d_pre.device, scratch.get("colsum_ws"))
         ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre,
                     colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
-        wgrad_async(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
+        wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
         d_ln2 = torch.empty_like(ln2)
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
         del d_pre
         dx, dx_lp = ops.layernorm_bwd(d_ln2, x_mid, blk.norm2.weight, mean2, rstd2, dx, g[pfx + "norm2.weight"],
                                       g[pfx + "norm2.bias"], True, dcolsum=g[pfx + "attn.proj.bias"])
         # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))      (proj.bias gradient came out of LN2' above)
-        wgrad_async(dx_lp, att, g[pfx + "attn.proj.weight"], None)
+        wgrad(dx_lp, att, g[pfx + "attn.proj.weight"], None)
         d_att = torch.empty_like(att)
         ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
         if not last:
@@ -402,7 +418,7 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
                                       dcolsum=g[f"blocks.{i - 1}.mlp.fc2.bias"] if i > 0 else None)
         # last weight gradient of the block; the side stream (ordered after the LayerNorm gradients above)
         # then reports the block complete, so its all-reduce bucket starts without stalling the main stream
-        wgrad_async(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], done=i)
+        wgrad(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], done=i)
     # ---- patch embedding / positional parameters / prefix tokens
     Tpe, Fpe = model.time_new_pos_embed.shape[-1], model.freq_new_pos_embed.shape[-2]
     dpatch = ops.patch_bwd(dx.view(B, Ntok, D), ctx["pf"], ctx["pt"], ctx["toff"], Tpe, Fpe, g["cls_token"],

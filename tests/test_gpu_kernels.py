@@ -545,3 +545,24 @@ def test_persistent_gemm_edge_shapes(tune, M, N, K):
             assert rel_err(part.sum(0), acc) < 3e-3, split
     finally:
         ops.GEMM_TUNE = old
+
+
+def test_wgrad_tn_batched_matches_single_launches():
+    """pa_gemm_tn_batched + pa_reduce_partials_batched: four weight gradients (different shapes, one with only a few
+    token rows, one accumulating) in one launch each == the per-problem path."""
+    dt = PA_BF16
+    shapes = [(1500, 768, 768), (1500, 2304, 768), (1500, 768, 3072), (130, 3072, 768)]   # (tokens, N, K)
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dY = rnd(M, N, seed=90 + i).to(TD[dt]).to(DEV)
+        X = rnd(M, K, seed=95 + i).to(TD[dt]).to(DEV)
+        out = torch.full((N, K), 0.5 if i == 1 else 7.0, device=DEV)
+        probs.append((dY, X, out, i == 1))
+        refs.append(dY.double().cpu().T @ X.double().cpu() + (0.5 if i == 1 else 0.0))
+    ops.wgrad_tn_batched(probs, dt)
+    torch.cuda.synchronize()
+    for (dY, X, out, acc), ref in zip(probs, refs):
+        assert rel_err(out, ref) < 3e-3
+        single = torch.full_like(out, 0.5 if acc else 7.0)
+        ops.wgrad_tn(dY, X, single, dt, acc)
+        assert rel_err(out, single.double().cpu()) < 1e-5     # same products, different split-K grouping
