@@ -359,11 +359,13 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         if pending is None:
             return wgrad_async(dY, X, dW, db, done)
         pending.append((dY, X, dW.view(dY.shape[1], -1), False))
-        if db is not None:
+        if db is not None and done is None:
             ops.colsum(dY, db)
         if done is not None:
             scratch["part"] = ops.wgrad_tn_batched(pending, dt, scratch.get("part"))
             pending.clear()
+            if db is not None:
+                ops.colsum(dY, db)          # right after the GEMM that just streamed dY through the cache
             if on_block_done:
                 on_block_done(done)
 
