@@ -12,6 +12,7 @@
 //
 // q/k/v are read in place from the qkv GEMM output [B*N][3*H*64]; o / dqkv are token-major.
 #include <algorithm>
+#include <type_traits>
 
 #include "pa_mma.h"
 
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const int k0 = blockIdx.x * 128 + wave * 32;
     const int key = k0 + (lane & 31);
     const int krow = min(key, N - 1);
+    const bool active = k0 < N;                                 // wave-uniform
 
     typename Frag<T>::type kf[Tile<T>::NFRAG], vf[Tile<T>::NFRAG];
 #pragma unroll
@@ -337,8 +339,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const char* sDO = sQ + Tile<T>::BYTES;
         const float* sLse = (const float*)(sQ + 2 * Tile<T>::BYTES);
         const float* sDelta = sLse + TROWS;
+        if (!active) continue;          // all 32 keys of this wave are past N: stage and meet barriers only
+        const bool half_tile = qt == ntiles - 1 && qt * TROWS + 32 >= nq;     // second 32 queries of the tile do not exist
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            if (qb == 1 && half_tile) continue;
             f32x16 sa, dpa;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dpa[r] = 0.f; }
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int q = q0 + (lane & 31);
     const int qrow = min(q, nq - 1);
+    const bool active = q0 < nq;                                // wave-uniform
 
     typename Frag<T>::type qf[Tile<T>::NFRAG], dof[Tile<T>::NFRAG];
 #pragma unroll
@@ -474,8 +480,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         if (kt + 1 < ntiles) stage((kt + 1) & 1, kt + 1);
         const char* sK = smem + (kt & 1) * (2 * Tile<T>::BYTES);
         const char* sV = sK + Tile<T>::BYTES;
+        if (!active) continue;          // all 32 queries of this wave are past nq
+        const bool half_tile = kt == ntiles - 1 && kt * TROWS + 32 >= N;      // second 32 keys of the tile do not exist
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && half_tile) continue;
             f32x16 sa, dpa;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dpa[r] = 0.f; }

@@ -27,6 +27,25 @@ static constexpr int BM = 128, BN = 128, KB = 128;  // KB: K bytes per step
 static constexpr int TILE_BYTES = BM * KB;            // 16 KiB per operand tile
 static constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;   // 64 KiB (TN kernel)
 
+// ---- probe build only (-DPA_PROBE -> libpasst_amd_probe.so, tools/probe_epilogue.py): s_memtime stamps of the
+// role-split kernel's item timeline and switches that remove parts of the epilogue (pa_gemm_args.reserved:
+// bit 0 = no global stores, bit 1 = no epilogue at all).  The product library is built without it.
+#ifdef PA_PROBE
+__device__ unsigned long long* g_probe_buf = nullptr;
+static constexpr int PROBE_SLOTS = 512;
+// stamps go to LDS (past G::LDS) so that they add no global store to the vmcnt queue being measured; the kernel copies
+// them out once at its end
+#define PA_PROBE_STAMP(cond, idx)                                                                             \
+    do {                                                                                                      \
+        if ((cond) && (wave & 3) == 0 && lane == 0 && (idx) < PROBE_SLOTS)                                    \
+            ((unsigned long long*)(smem + G::LDS))[(wave >> 2) * PROBE_SLOTS + (idx)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define PA_PROBE_FLAG(a, bit) (((a).reserved >> (bit)) & 1)
+#else
+#define PA_PROBE_STAMP(cond, idx) do {} while (0)
+#define PA_PROBE_FLAG(a, bit) 0
+#endif
+
 
 
 // Shared epilogue: the TM x 2 MFMA accumulators of this wave (TM*32 x 64 outputs at rows m0 + wr*TM*32,
@@ -76,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
     f32x4 xr[P > 0 ? P : 1][4][NV];
     auto pass_row = [&](int i, int it) {
         const int m = m0 + wr * (TM * 32) + i * 32 + it * 8 + erow;
-        return (m < a.M && colok) ? m : -1;
+        return (m < a.M && colok && !PA_PROBE_FLAG(a, 0)) ? m : -1;
     };
     auto load_aux = [&](int slot, int i) {
         if constexpr (P > 0) {
@@ -198,6 +217,17 @@ __device__ __forceinline__ void gemm_epilogue_f32_direct(const pa_gemm_args& a, 
     }
     float* outp = RES ? a.out_f32 : a.out_f32 + (int64_t)split * a.M * a.ldo32;
     const bool full = mb + TM * 32 <= a.M && n0 + wc * 64 + 64 <= a.N && !(RES && a.row_mod > 0);
+#ifdef PA_PROBE
+    if (PA_PROBE_FLAG(a, 0)) {          // no global traffic: keep the accumulators live, touch nothing
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        return;
+    }
+#endif
     if (full) {
         // one uniform base per tile (SGPRs) + 32-bit per-lane offsets; the row term of the offset is uniform and
         // added on the fly, so nothing per row has to stay live
@@ -490,6 +520,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         tile_coords(item - sp * nwg, tiles_m, tiles_n, PA_NT_GROUP_M, tm, tn);
         tab[r] = make_int4(tm * TBM, tn * TBN, sp, 0);
     }
+#ifdef PA_PROBE
+    for (int i = tid; i < 2 * PROBE_SLOTS; i += 512) ((unsigned long long*)(smem + G::LDS))[i] = 0ull;
+#endif
     __syncthreads();
     // DMA cursor of the item whose K-tiles are being fetched: a uniform 64-bit base per operand (SGPRs: tile
     // origin + K offset) plus per-lane 32-bit offsets (row within the tile, clamped at the matrix edge, and the
@@ -571,6 +604,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
         if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
+        PA_PROBE_STAMP(round < 24, round * 16);
 
         for (int t = 0; t < nsteps; ++t) {
             const char* sA = smem + gbuf * STAGE_BYTES;
@@ -616,12 +650,20 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 __builtin_amdgcn_s_barrier();
             }
             gbuf ^= 1;
+            PA_PROBE_STAMP(round < 24 && t < 13, round * 16 + 1 + t);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align the two groups: every fragment read is done
         // slabs go into the ring slot that was read last (gbuf now names the one holding the next item's tile 0)
         float* slab = (float*)(wave < G::SLABS_IN_STAGE ? smem + (gbuf ^ 1) * STAGE_BYTES + wave * SLAB_BYTES
                                                         : smem + 2 * STAGE_BYTES + (wave - G::SLABS_IN_STAGE) * SLAB_BYTES);
-        if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
+        if (PA_PROBE_FLAG(a, 1)) {             // probe: no epilogue at all (accumulators kept live)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        } else if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
             (void)slab;
             gemm_epilogue_f32_direct<EPI, TM>(a, acc, HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr, cur_m0,
                                               cur_n0, cur_split, wr, wc, lane);
@@ -639,6 +681,14 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             }
             gemm_epilogue<T, EPI, TM>(a, acc, slab, cur_m0, cur_n0, cur_split, wr, wc, lane, bias8, (cur_m0 / TBM) * 2 + wr);
         }
+        PA_PROBE_STAMP(round < 24, round * 16 + 15);
+#ifdef PA_PROBE
+        if (!have_next && g_probe_buf && blockIdx.x < 8) {
+            __syncthreads();
+            for (int i = tid; i < 2 * PROBE_SLOTS; i += 512)
+                g_probe_buf[blockIdx.x * 2 * PROBE_SLOTS + i] = ((const unsigned long long*)(smem + G::LDS))[i];
+        }
+#endif
         if (!have_next) break;
         // (re)derive the DMA cursor of the item just started: cheaper than carrying it through the epilogue
         ++round;
@@ -661,12 +711,17 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     // an empty K split, or more rounds than the item table holds: the generic kernel handles it
     if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps || cdiv(total, 256) > G::MAX_ROUNDS)
         return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+#ifdef PA_PROBE
+    constexpr int LDS_BYTES = G::LDS + 2 * PROBE_SLOTS * 8;
+#else
+    constexpr int LDS_BYTES = G::LDS;
+#endif
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(std::min(total, 256)), dim3(512), G::LDS, st, a, tiles_m,
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
                        tiles_n, nwg, per, total);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
@@ -1058,6 +1113,9 @@ struct TnBatch {
     int32_t n;
 };
 __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBatch b) {
+    // (r02: dealing the items slice-major so that an XCD's ~32 resident workgroups share one token slice -- every dY / X
+    // panel stage fetched once per XCD -- measured 3-4 % SLOWER than this problem-major order, 374 vs 360 us per launch:
+    // the kernel is not bound by the fabric)
     int p = 0;
     while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
     const int item = blockIdx.x - b.first[p];
@@ -1535,3 +1593,12 @@ extern "C" int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, in
                        : hipMemset2DAsync(ptr, (size_t)pitch_bytes, 0, (size_t)width_bytes, (size_t)rows, (hipStream_t)stream);
     return e == hipSuccess ? PA_OK : set_hip_error(e);
 }
+
+#ifdef PA_PROBE
+// probe library only: where the role-split kernel writes its s_memtime stamps (NULL = off)
+extern "C" int pa_probe_set_buffer(void* dev_buf) {
+    unsigned long long* p = (unsigned long long*)dev_buf;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(pa::g_probe_buf), &p, sizeof(p));
+    return e == hipSuccess ? PA_OK : pa::set_hip_error(e);
+}
+#endif

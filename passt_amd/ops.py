@@ -33,6 +33,7 @@ def _p(t):
 # {epilogue: [(start_event, end_event, algorithmic_flops)]}
 GEMM_PROFILE = None
 GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
+GEMM_RESERVED = 0      # pa_gemm_args.reserved (ignored by the product library; probe builds: tools/probe_epilogue.py)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
 
 
@@ -147,6 +148,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
     a.tune = GEMM_TUNE
+    a.reserved = GEMM_RESERVED
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out), _p(colsum_ws), int(colsum_accumulate)
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
