@@ -284,6 +284,264 @@ __device__ __forceinline__ void gemm_epilogue_f32_direct(const pa_gemm_args& a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue v2 (r02) of the role-split kernels.  The first version was bound by its own instruction stream, not by the
+// stores (profiles/r02_epilogue_probe.json: 5.4k cycles STORE / 15.3k GELU per item whatever the other CUs do): LDS write
+// issue (ds_write_b32 moves 64 B/clk per CU), exec-mask branches around every 8 rows, 64-bit address arithmetic per
+// access, dword-per-lane accesses for the f32 residual (1 536 vector-memory instructions of 256 bytes per 192x256 tile).
+// This version is straight-line code:
+//  * global accesses are BUFFER instructions: one descriptor per operand whose base is the wave tile's origin and whose
+//    size is the bytes from there to the end of the matrix; the offset is a 32-bit VGPR (lane part + row term, one
+//    v_add).  Rows past M and lanes whose 8 (4) columns are past N fall outside the descriptor: the hardware drops
+//    those stores and returns 0 for those loads -- no predicate, no branch, edge tiles run the same code.
+//  * bf16 outputs (STORE / GELU / DGELU): all math is done in the ACCUMULATOR layout, where registers r, r+1 (r even) of
+//    a 32x32 block are two consecutive rows of one column: bias / GELU / GELU' work on such pairs and
+//    v_cvt_pk_bf16_f32 packs the pair into ONE dword, written with one ds_write_b32 into a "row-pair" slab:
+//        dword(p, c) = {row 2p, row 2p+1} of column c   at byte  p*256 + (((c>>2) ^ ((p>>1)&1)) << 4) + (c&3)*4
+//    (16 pairs x 64 columns = 4 KiB per 32x64 pass: HALF the LDS write instructions; the XOR makes the ds_read_b128
+//    below conflict free).  A lane then reads the 8 dwords of (pair p, columns 8g..8g+7), splits them with 8 v_perm_b32
+//    into row 2p and row 2p+1 (8 bf16 = 16 bytes each) and stores two 16-byte vectors: 8 lanes cover a 128-byte row
+//    segment.  PA_EPI_DGELU reads its pre-activation rows the same way in reverse: 16-byte row vectors -> interleaved
+//    pair dwords -> slab -> ds_read_b32 in the accumulator layout; the column sums (fc1.bias gradient) are lane-local.
+//  * f32 outputs (RESID): [32][64] f32 slab, no padding and no swizzle needed (writes: 32 lanes = 32 consecutive
+//    columns of a row; reads: one 16-byte slot per lane, 16 lanes = one row, 4 rows per instruction); the residual rows
+//    and the outputs move as 16-byte vectors, 4x fewer vector-memory instructions than the dword-per-lane form.
+// ------------------------------------------------------------------------------------------------
+#ifndef PA_EPILOGUE_V2
+#define PA_EPILOGUE_V2 1
+#endif
+#ifndef PA_V2_DEPTH
+#define PA_V2_DEPTH 2          // 32-row passes of auxiliary rows (residual / pre-activation) requested ahead of their use
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_bits_t;
+__device__ __forceinline__ uint32_t perm_lo16(uint32_t hi_src, uint32_t lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u); }
+__device__ __forceinline__ uint32_t perm_hi16(uint32_t hi_src, uint32_t lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return __builtin_bit_cast(uint32_t, bf16x2{(bf16)lo, (bf16)hi}); }
+
+// descriptor over [origin, origin + bytes): uniform arguments only (the tile origin comes from SGPRs)
+__device__ __forceinline__ auto tile_rsrc(const void* origin, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, n, 0x00020000);
+}
+static constexpr uint32_t V2_OOB = 0x80000000u;     // a lane offset no descriptor of < 2 GiB contains
+
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* slab, const float* bias_row,
+                                                      int m0, int n0, int wr, int wc, int lane, int colsum_row) {
+    static_assert(EPI == PA_EPI_STORE || EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU, "bf16 outputs");
+    const int h = lane >> 5, c = lane & 31;
+    const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;          // uniform: origin of this wave's tile
+    if (mb >= a.M || nb >= a.N) {                                  // uniform: nothing of this wave tile exists
+        if constexpr (EPI == PA_EPI_DGELU) {                       // ... but its row of column-sum partials is summed later
+            if (a.colsum_out && nb < a.N && lane < 32) {
+                float* cw = a.colsum_ws + (int64_t)colsum_row * a.N + nb + c;
+                if (nb + c < a.N) cw[0] = 0.f;
+                if (nb + 32 + c < a.N) cw[32] = 0.f;
+            }
+        }
+        return;
+    }
+    // slab addresses: writes in the accumulator layout (pair k of block j: + j*128 + ((k&1) + 4*(k>>1))*256),
+    // reads of task t = 0,1 (pair p = (lane>>3) + 8t, column group g = lane&7: + t*2048)
+    char* const wbase = slab + 2 * h * 256 + (((c >> 2) ^ h) << 4) + (c & 3) * 4;
+    const int g = lane & 7, fsw = (lane >> 4) & 1;
+    char* const r0 = slab + (lane >> 3) * 256 + (((2 * g) ^ fsw) << 4);
+    char* const r1 = slab + (lane >> 3) * 256 + (((2 * g + 1) ^ fsw) << 4);
+    float b2[2] = {0.f, 0.f};
+    if constexpr (EPI != PA_EPI_DGELU) {
+        if (bias_row) { b2[0] = bias_row[wc * 64 + c]; b2[1] = bias_row[wc * 64 + 32 + c]; }
+    }
+    const bool colok = nb + g * 8 < a.N;                              // N % 8 == 0: all 8 columns of the lane in or out
+    const uint32_t ld2 = (uint32_t)a.ldolp * 2u;
+    const auto ors = tile_rsrc((const char*)a.out_lp + ((int64_t)mb * a.ldolp + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp + (a.N - nb)) * 2);
+    const uint32_t vo = colok ? (uint32_t)(2 * (lane >> 3)) * ld2 + (uint32_t)g * 16u : V2_OOB;
+    uint32_t ld2b = 0, vo2 = 0;
+    auto ors2 = ors;
+    if constexpr (EPI == PA_EPI_GELU) {
+        ld2b = (uint32_t)a.ldolp2 * 2u;
+        ors2 = tile_rsrc((const char*)a.out_lp2 + ((int64_t)mb * a.ldolp2 + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp2 + (a.N - nb)) * 2);
+        vo2 = colok ? (uint32_t)(2 * (lane >> 3)) * ld2b + (uint32_t)g * 16u : V2_OOB;
+    }
+    uint32_t ldx2 = 0, vx = 0;
+    auto xrs = ors;
+    constexpr int XD = EPI == PA_EPI_DGELU ? (PA_V2_DEPTH < TM ? PA_V2_DEPTH : TM) : 1;
+    constexpr int XOFF = 4096;         // DGELU: the pre-activation goes through the second half of the wave's slab
+    u32x4 xr[XD][2][2];
+    auto load_x = [&](int slot, int i) {        // pre-activation row vectors of pass i (rows 2p, 2p+1 of task t)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                xr[slot][t][q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx + (uint32_t)(i * 32 + 16 * t + q) * ldx2, 0, 0);
+    };
+    if constexpr (EPI == PA_EPI_DGELU) {
+        ldx2 = (uint32_t)a.ldaux * 2u;
+        xrs = tile_rsrc((const char*)a.aux + ((int64_t)mb * a.ldaux + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldaux + (a.N - nb)) * 2);
+        vx = colok ? (uint32_t)(2 * (lane >> 3)) * ldx2 + (uint32_t)g * 16u : V2_OOB;
+#pragma unroll
+        for (int i = 0; i < XD; ++i) load_x(i, i);
+    }
+    float csum[2] = {0.f, 0.f};
+    // The passes are software pipelined by hand: the LDS round trip (and, for DGELU, the pre-activation's way into the
+    // accumulator layout) of one pass runs under the polynomial math of the next one -- the epilogue is VALU bound (GELU:
+    // ~14 VALU per output, 128 outputs per lane, two waves per SIMD) and the two waves of a SIMD run in step, so
+    // whatever is not overlapped inside a wave is not overlapped at all.
+    auto x_to_slab = [&](int i) {      // DGELU: pre-activation rows of pass i -> pair dwords -> slab (two 16-byte writes per task)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 x0 = xr[i % XD][t][0], x1 = xr[i % XD][t][1];      // rows 2p, 2p+1; dword q = columns 8g+2q, 8g+2q+1
+            const u32x4 e0 = {perm_lo16(x1[0], x0[0]), perm_hi16(x1[0], x0[0]), perm_lo16(x1[1], x0[1]), perm_hi16(x1[1], x0[1])};
+            const u32x4 e1 = {perm_lo16(x1[2], x0[2]), perm_hi16(x1[2], x0[2]), perm_lo16(x1[3], x0[3]), perm_hi16(x1[3], x0[3])};
+            *(u32x4*)(r0 + XOFF + t * 2048) = e0;
+            *(u32x4*)(r1 + XOFF + t * 2048) = e1;
+        }
+    };
+    uint32_t xw[2][8];                 // DGELU: pre-activation pairs of the pass about to be computed, accumulator layout
+    auto x_from_slab = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xw[j][k] = *(const uint32_t*)(wbase + XOFF + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
+    };
+    uint32_t pk[2][8], pk2[2][8];
+    auto math = [&](int i) {           // accumulators of pass i -> packed bf16 pairs (and the activation / the product with GELU')
+        const int rows_left = a.M - mb - i * 32;       // rows of this pass that exist (uniform): only the column sums need it
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                f32x2 v = {acc[i][j][2 * k] + b2[j], acc[i][j][2 * k + 1] + b2[j]};
+                if constexpr (EPI == PA_EPI_DGELU) {
+                    const f32x2 x = {__builtin_bit_cast(float, xw[j][k] << 16), __builtin_bit_cast(float, xw[j][k] & 0xffff0000u)};
+                    v = v * (PA_PROBE_FLAG(a, 2) ? x : gelu_grad_fast2(x));
+                    if (rows_left >= 32) {
+                        csum[j] += v[0] + v[1];
+                    } else {         // last row tile of the matrix: rows >= M hold duplicates of row M-1
+                        const int row = 2 * ((k & 1) + 4 * (k >> 1) + 2 * h);
+                        csum[j] += (row < rows_left ? v[0] : 0.f) + (row + 1 < rows_left ? v[1] : 0.f);
+                    }
+                }
+                pk[j][k] = cvt_pk_bf16(v[0], v[1]);
+                if constexpr (EPI == PA_EPI_GELU) {
+                    const f32x2 gl = PA_PROBE_FLAG(a, 2) ? v : gelu_fast2(v);     // of the f32 value (the reference applies GELU before rounding too)
+                    pk2[j][k] = cvt_pk_bf16(gl[0], gl[1]);
+                }
+            }
+    };
+    if constexpr (EPI == PA_EPI_DGELU) {
+        x_to_slab(0);
+        if (XD < TM) load_x(0, XD);
+        x_from_slab();
+    }
+    math(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        // pass i: packed pairs -> slab; its row reads are issued right away ...
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                *(uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk[j][k];
+                if constexpr (EPI == PA_EPI_GELU) *(uint32_t*)(wbase + 4096 + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk2[j][k];
+            }
+        // same-wave LDS accesses execute in order: no barrier between the writes and the reads
+        u32x4 d[EPI == PA_EPI_GELU ? 2 : 1][2][2];
+#pragma unroll
+        for (int o = 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                d[o][t][0] = *(const u32x4*)(r0 + o * 4096 + t * 2048);
+                d[o][t][1] = *(const u32x4*)(r1 + o * 4096 + t * 2048);
+            }
+        if constexpr (EPI == PA_EPI_DGELU) {
+            if (i + 1 < TM) {
+                x_to_slab(i + 1);
+                if (i + 1 + XD < TM) load_x((i + 1) % XD, i + 1 + XD);
+                x_from_slab();
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and land under the math of pass i+1
+        if (i + 1 < TM) math(i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 d0 = d[o][t][0], d1 = d[o][t][1];
+                const u32x4 lo = {perm_lo16(d0[1], d0[0]), perm_lo16(d0[3], d0[2]), perm_lo16(d1[1], d1[0]), perm_lo16(d1[3], d1[2])};
+                const u32x4 hi = {perm_hi16(d0[1], d0[0]), perm_hi16(d0[3], d0[2]), perm_hi16(d1[1], d1[0]), perm_hi16(d1[3], d1[2])};
+                const uint32_t ldb = o ? ld2b : ld2;
+                const uint32_t off = (PA_PROBE_FLAG(a, 0) ? V2_OOB : (o ? vo2 : vo)) + (uint32_t)(i * 32 + 16 * t) * ldb;
+                __builtin_amdgcn_raw_buffer_store_b128(lo, o ? ors2 : ors, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(hi, o ? ors2 : ors, off + ldb, 0, 0);
+            }
+    }
+    if constexpr (EPI == PA_EPI_DGELU) {
+        if (a.colsum_out) {       // this lane holds the sums of 16 of the 32 rows of each block: the other half is lane ^ 32
+#pragma unroll
+            for (int j = 0; j < 2; ++j) csum[j] += __shfl_xor(csum[j], 32, 64);
+            if (lane < 32) {
+                float* cw = a.colsum_ws + (int64_t)colsum_row * a.N + nb + c;
+                if (nb + c < a.N) cw[0] = csum[0];
+                if (nb + 32 + c < a.N) cw[32] = csum[1];
+            }
+        }
+    }
+}
+
+// f32 residual epilogue through LDS: out[m][n] = acc + bias[n] + resid[m][n]
+template <int TM>
+__device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* slab, const float* bias_row,
+                                                       int m0, int n0, int wr, int wc, int lane) {
+    const int h = lane >> 5, c = lane & 31;
+    const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
+    if (mb >= a.M || nb >= a.N) return;
+    char* const wbase = slab + 4 * h * 256 + c * 4;                    // + ((r&3) + 8*(r>>2))*256 + j*128
+    const int er = lane >> 4, sl = lane & 15;
+    const char* const rdbase = slab + er * 256 + sl * 16;              // + it*1024
+    float b2[2] = {0.f, 0.f};
+    if (bias_row) { b2[0] = bias_row[wc * 64 + c]; b2[1] = bias_row[wc * 64 + 32 + c]; }
+    const bool colok = nb + sl * 4 < a.N;                              // ld % 4 == 0 and N % 8 == 0: the lane's 4 columns are all in or out
+    const uint32_t ldr4 = (uint32_t)a.ldr * 4u, ldo4 = (uint32_t)a.ldo32 * 4u;
+    const auto rrs = tile_rsrc((const char*)a.resid + ((int64_t)mb * a.ldr + nb) * 4, ((int64_t)(a.M - mb - 1) * a.ldr + (a.N - nb)) * 4);
+    const auto ors = tile_rsrc((const char*)a.out_f32 + ((int64_t)mb * a.ldo32 + nb) * 4, ((int64_t)(a.M - mb - 1) * a.ldo32 + (a.N - nb)) * 4);
+    const uint32_t vr = colok ? (uint32_t)er * ldr4 + (uint32_t)sl * 16u : V2_OOB, vo = colok ? (uint32_t)er * ldo4 + (uint32_t)sl * 16u : V2_OOB;
+    // residual rows: DEPTH half passes (16 rows = 4 vectors per lane) are requested ahead of their use
+    constexpr int NH = 2 * TM, DEPTH = 2 * PA_V2_DEPTH < NH ? 2 * PA_V2_DEPTH : NH;
+    f32x4 xr[DEPTH][4];
+    auto load_half = [&](int slot, int hp) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            xr[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr + (uint32_t)(hp * 16 + it * 4) * ldr4, 0, 0));
+    };
+#pragma unroll
+    for (int hp = 0; hp < DEPTH; ++hp) load_half(hp, hp);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);       // keep the passes apart (register pressure)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *(float*)(wbase + ((r & 3) + 8 * (r >> 2)) * 256 + j * 128) = acc[i][j][r] + b2[j];
+        // same-wave LDS accesses execute in order: no barrier between the writes and the reads
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hp = 2 * i + hh;
+            f32x4 o[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) o[it] = *(const f32x4*)(rdbase + (hh * 4 + it) * 1024) + xr[hp % DEPTH][it];
+            __builtin_amdgcn_sched_barrier(0);   // the refill must not be hoisted above the adds (it would get fresh registers)
+            if (hp + DEPTH < NH) load_half(hp % DEPTH, hp + DEPTH);
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[it]), ors, vo + (uint32_t)(hp * 16 + it * 4) * ldo4, 0, 0);
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most `k * PER` of this wave's global->LDS copies are still in flight (k = 0..3)
 template <int PER> __device__ __forceinline__ void wait_vm_groups(int k) {
@@ -663,6 +921,12 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        } else if constexpr (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL) {
+            // straight-line epilogue; matrix edges are handled by the buffer descriptors (launch_gemm_stagger keeps the
+            // row-remapped patch-embedding form and matrices >= 2 GiB away from this kernel)
+            const float* brow = HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr;
+            if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane);
+            else gemm_epilogue_v2_bf16<EPI, TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr);
         } else if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
             (void)slab;
             gemm_epilogue_f32_direct<EPI, TM>(a, acc, HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr, cur_m0,
@@ -708,8 +972,14 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     const int total = nwg * splits;
-    // an empty K split, or more rounds than the item table holds: the generic kernel handles it
-    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps || cdiv(total, 256) > G::MAX_ROUNDS)
+    // an empty K split, or more rounds than the item table holds: the generic kernel handles it.  So does it handle what
+    // the buffer-descriptor epilogue (v2) does not cover: the row-remapped residual form (patch embedding) and
+    // matrices whose rows do not all lie within 2 GiB of the first one
+    const int64_t lim = (int64_t)1 << 31;
+    const bool big = (int64_t)a.M * a.ldolp * 2 >= lim || (int64_t)a.M * a.ldolp2 * 2 >= lim || (int64_t)a.M * a.ldaux * 2 >= lim ||
+                     (int64_t)a.M * a.ldr * 4 >= lim || (int64_t)a.M * a.ldo32 * 4 >= lim;
+    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps || cdiv(total, 256) > G::MAX_ROUNDS ||
+        (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && (big || (EPI == PA_EPI_RESID && a.row_mod > 0))))
         return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
 #ifdef PA_PROBE
     constexpr int LDS_BYTES = G::LDS + 2 * PROBE_SLOTS * 8;

@@ -56,14 +56,16 @@ def main():
             ops.GEMM_TUNE = tune
             rec = {"gemm": name, "N": Nn, "K": K, "tune": tune}
             lib.pa_probe_set_buffer(None)
-            for flag, label in ((0, "full"), (1, "no_global"), (2, "no_epilogue")):
+            for flag, label in ((0, "full"), (1, "no_stores"), (4, "no_act_math"), (5, "no_stores_no_math"), (2, "no_epilogue")):
                 ops.GEMM_RESERVED = flag
                 sec = timeit(lambda: ops.gemm_nt(A, W, PA_BF16, epi, **kw), 15)
                 rec[label + "_us"] = round(sec * 1e6, 1)
             ops.GEMM_RESERVED = 0
+            ops.GEMM_RESERVED = int(os.environ.get("PROBE_STAMP_FLAGS", "0"))
             buf.zero_()
             lib.pa_probe_set_buffer(buf.data_ptr())
             ops.gemm_nt(A, W, PA_BF16, epi, **kw)
+            ops.GEMM_RESERVED = 0
             torch.cuda.synchronize()
             lib.pa_probe_set_buffer(None)
             st = buf.cpu().numpy().reshape(8, 2, SLOTS)
