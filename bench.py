@@ -17,6 +17,12 @@ Besides the contract line it reports
   roofline     : the dominant kernel (the MFMA GEMM family), timed per launch with HIP events on the
                  launch stream inside the timed region; achieved = algorithmic FLOPs / measured time,
                  against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md).
+  attention    : the fused attention kernels, timed the same way in the same run (MFMA utilisation).
+  frontend     : the mel front-end kernel: algorithmic GB/s against the 8 TB/s HBM peak.
+  scaling_model: a MODELLED 2/4/8-GPU curve from this run's step time and the reducer's bucket sizes
+                 (the measured curve is the driver's SCALE_rNN.json when it has an 8-GPU node).
+--config c4 | c4_ref | c5 runs the other BASELINE.json configurations (ViT-L geometry, the reference's passt_l,
+ESC-50 fine-tune); their lines are committed under profiles/.
   cpu_baseline : the oracle (CPU restatement of the reference, oracle/passt_oracle.py) timed on this
                  host on a bounded sample of the same workload (train-mode fwd+bwd, B=4 per iteration).
 """
@@ -35,8 +41,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0              # same guide
 ARCH = "passt_s_swa_p16_128_ap476"
 CLIP_SAMPLES = 320000                # 10 s @ 32 kHz
+
+# BASELINE.json configs.  The driver's line (no --config) is c2, the configuration the metric is quoted on; the others
+# are run by hand and their lines are committed under profiles/ (bench lines, not parity cases).
+#   tokens = kept patches + 2; dims = (embed_dim, depth, heads)
+CONFIGS = {
+    "c2": dict(metric="clips/s (10s@32k) fwd+bwd passt_s", arch=ARCH, net_kw=dict(s_patchout_t=40, s_patchout_f=4), custom=None,
+               n_classes=527, batch=64, clip=CLIP_SAMPLES, loss="bce", dims=(768, 12, 12), tokens=474, kept=472,
+               mel_kw=dict(freqm=48, timem=192),
+               desc="passt_s_swa_p16_128_ap476 train step (mel front end + mixup + fwd + BCE + bwd + {opt}), 768/12/12, "
+                    "474 tokens (s_patchout_t=40,f=4), random-init weights"),
+    "c4": dict(metric="clips/s (10s@32k) fwd+bwd ViT-L/16 (1024/24/16) u_patchout=400", arch=None,
+               custom=dict(embed_dim=1024, depth=24, num_heads=16, u_patchout=400), net_kw={}, n_classes=527, batch=32,
+               clip=CLIP_SAMPLES, loss="bce", dims=(1024, 24, 16), tokens=790, kept=788, mel_kw=dict(freqm=48, timem=192),
+               desc="BASELINE config #4: ViT-L/16 geometry 1024/24/16, u_patchout=400 (790 tokens), train step (mel + mixup + "
+                    "fwd + BCE + bwd + {opt}), random-init weights"),
+    "c4_ref": dict(metric="clips/s (10s@32k) fwd+bwd passt_l (768/7/12) u_patchout=400", arch="passt_l_kd_p16_128_ap47",
+                   net_kw=dict(u_patchout=400), custom=None, n_classes=527, batch=32, clip=CLIP_SAMPLES, loss="bce",
+                   dims=(768, 7, 12), tokens=790, kept=788, mel_kw=dict(freqm=48, timem=192),
+                   desc="the reference's own passt_l (passt_l_kd_p16_128_ap47: 768/7/12), u_patchout=400 (790 tokens), train "
+                        "step (mel + mixup + fwd + BCE + bwd + {opt}), random-init weights"),
+    "c5": dict(metric="clips/s (5s@32k) fwd+bwd passt_s ESC-50 fine-tune", arch=ARCH, net_kw=dict(s_patchout_t=10, s_patchout_f=3),
+               custom=None, n_classes=50, batch=12, clip=160000, loss="ce", dims=(768, 12, 12), tokens=353, kept=351,
+               mel_kw=dict(freqm=48, timem=80),
+               desc="BASELINE config #5: ESC-50 fine-tune (ex_esc50.py:40,60-64): passt_s n_classes=50, 5 s clips (500 frames, "
+                    "random time-pos-embed offset), s_patchout_t=10,f=3 (353 tokens), CE-mixup loss, train step incl. {opt}"),
+}
 
 
 PROFILE_EVERY = 5      # timed steps between two steps that carry per-launch HIP events
@@ -47,6 +80,26 @@ def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
     fwd+bwd = 3x fwd."""
     fwd = depth * (24 * N * D * D + 4 * N * N * D) + 2 * kept_patches * 256 * D
     return 3 * fwd / 1e9
+
+
+def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7):
+    """MODELLED (not measured) weak-scaling curve for N = 2, 4, 8 GPUs of one node from the measured single-GPU step and
+    the measured per-bucket wire bytes: ring all-reduce of S bytes moves 2 (N-1)/N S per GPU; xGMI is point-to-point,
+    a ring uses one link per direction, RCCL runs one ring per link it can (min(N-1, links) of 153 GB/s each).  Every
+    bucket but the LAST overlaps with the backward; the last one is exposed, minus the optimizer launches of the earlier
+    buckets that now run under it (TrainStep drains buckets in order).  Efficiency = t1 / tN."""
+    sizes = list(bucket_bytes.values())
+    total, last = sum(sizes), sizes[-1] + (sizes[-2] if len(sizes) > 1 else 0)     # block 0 and patch-embedding buckets
+    out = {}
+    for n in (2, 4, 8):
+        bw = min(n - 1, links) * link_gbps * 1e9 * 0.35         # RCCL's large-message bus bandwidth is ~1/3 of the aggregate link peak
+        t_all = 2.0 * (n - 1) / n * total / bw * 1e3            # ms on the wire per step
+        t_last = 2.0 * (n - 1) / n * last / bw * 1e3
+        bwd_window = 0.6 * ms_step_1gpu                         # the backward is ~60 % of the step
+        exposed = max(0.0, t_all - t_last - bwd_window) + max(0.0, t_last - 0.4)   # 0.4 ms of optimizer work covers the tail
+        out[str(n)] = {"wire_ms": round(t_all, 3), "exposed_ms": round(exposed, 3),
+                       "efficiency": round(ms_step_1gpu / (ms_step_1gpu + exposed), 4)}
+    return out
 
 
 def cpu_baseline(budget_s=12.0, threads=None):
@@ -83,7 +136,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS), help="BASELINE.json configuration (default c2 = the metric's)")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the configuration's)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events (measures their cost)")
@@ -111,27 +166,35 @@ def main():
     from passt_amd import ops
     from passt_amd.train import TrainStep
 
+    cfgd = CONFIGS[args.config]
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
     # module construction prints the reference's notices ("Warning: FMAX is None ..."): keep stdout for the ONE JSON line
     with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
         warnings.simplefilter("ignore")
-        net = passt_amd.get_model(arch=ARCH, pretrained=False, s_patchout_t=40, s_patchout_f=4).to(dev).train()
+        if cfgd["custom"] is not None:
+            net = passt_amd.PaSST(img_size=(128, 998), stride=10, num_classes=cfgd["n_classes"], distilled=True, **cfgd["custom"])
+        else:
+            net = passt_amd.get_model(arch=cfgd["arch"], pretrained=False, n_classes=cfgd["n_classes"], **cfgd["net_kw"])
+        net = net.to(dev).train()
         mel = None if args.no_mel else passt_amd.AugmentMelSTFT(
-            n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, freqm=48, timem=192, fmin=0.0, fmax=None,
-            fmin_aug_range=10, fmax_aug_range=2000).to(dev).train()      # ex_audioset.py:66-69 config
+            n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, fmin=0.0, fmax=None,
+            fmin_aug_range=10, fmax_aug_range=2000, **cfgd["mel_kw"]).to(dev).train()      # ex_audioset.py:66-69 / ex_esc50.py:62-66
     net.precision = args.precision
     net.overlap_wgrad = args.overlap_wgrad
-    if world > 1:                      # identical replicas
-        for p in net.parameters():
-            dist.broadcast(p.data, 0)
-    ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True)
-    B = args.batch
+    # TrainStep broadcasts rank 0's parameters itself (identical replicas)
+    ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
+                   loss=cfgd["loss"], comm_dtype=args.comm_dtype)
+    B = args.batch or cfgd["batch"]
+    frames = 998 if cfgd["clip"] == CLIP_SAMPLES else 1 + (cfgd["clip"] - 1) // 320     # --no-mel: the reference's speed-test shape
     if args.no_mel:
-        x = torch.randn(B, 1, 128, 998, device=dev)
+        x = torch.randn(B, 1, 128, frames, device=dev)
     else:
-        x = (torch.rand(B, 1, CLIP_SAMPLES, device=dev) * 2 - 1) * 0.1    # U(-1,1)*0.1
-    y = (torch.rand(B, 527, device=dev) < 2.7 / 527).float()              # ~2.7 labels per clip
+        x = (torch.rand(B, 1, cfgd["clip"], device=dev) * 2 - 1) * 0.1    # U(-1,1)*0.1
+    if cfgd["loss"] == "bce":
+        y = (torch.rand(B, cfgd["n_classes"], device=dev) < 2.7 / 527).float()      # ~2.7 labels per clip
+    else:
+        y = torch.randint(0, cfgd["n_classes"], (B,), device=dev)
 
     def barrier():
         if world > 1:
@@ -163,21 +226,29 @@ def main():
     if rank == 0:
         clips = world * B * args.steps
         value = clips / elapsed
-        gflop_clip = algorithmic_gflop_per_clip()
+        Dm, depth, _ = cfgd["dims"]
+        gflop_clip = algorithmic_gflop_per_clip(cfgd["tokens"], Dm, depth, cfgd["kept"])
         out = {
-            "metric": "clips/s (10s@32k) fwd+bwd passt_s", "value": round(value, 2), "unit": "clips/s",
+            "metric": cfgd["metric"], "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{ARCH} train step (mel front end + mixup + fwd + BCE + bwd + {args.optimizer}), "
-                                   f"768/12/12, 474 tokens (s_patchout_t=40,f=4), random-init weights",
+            "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "input": "spectrogram (B,1,128,998)" if args.no_mel else "waveform (B,1,320000) f32 resident in HBM"},
+                       "grad_wire_dtype": args.comm_dtype if world > 1 else None,
+                       "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
             "algorithmic_gflop_per_clip": round(gflop_clip, 2),
             "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
             "loss": round(loss_v, 6),
         }
         if prof:
+            n_prof_steps = len(range(0, args.steps, PROFILE_EVERY))
+            side = {}
+            for kind in ("attn_fwd", "attn_bwd", "mel"):
+                recs = prof.pop(kind, None)
+                if recs:
+                    ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+                    side[kind] = (len(recs), ms, sum(w for _, _, w in recs))
             tot_ms, tot_flop, n, per_kind = 0.0, 0.0, 0, {}
             for kind, recs in prof.items():
                 ms = sum(s.elapsed_time(e) for s, e, _ in recs)
@@ -188,15 +259,42 @@ def main():
                 tot_flop += fl
                 n += len(recs)
             achieved = tot_flop / tot_ms / 1e9
+            ms_step = 1e3 * elapsed / args.steps
+            # north_star: "MFMA utilisation for attention/MLP": the attention kernels, timed the same way in the same run
+            if "attn_fwd" in side and "attn_bwd" in side:
+                (nf, msf, wf), (nb, msb, wb) = side["attn_fwd"], side["attn_bwd"]
+                out["attention"] = {"bound": "mfma (co-bound by VALU: one exp per score, head dim 64)",
+                                    "fwd_avg_us": round(1e3 * msf / nf, 2), "fwd_tflops": round(wf / msf / 1e9, 1),
+                                    "bwd_avg_us": round(1e3 * msb / nb, 2), "bwd_tflops": round(wb / msb / 1e9, 1),
+                                    "achieved": round((wf + wb) / (msf + msb) / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": round((wf + wb) / (msf + msb) / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                    "flops": "algorithmic: 4 N^2 64 per head forward, 10 N^2 64 backward (5 products); "
+                                             "last block: 2 queries only",
+                                    "time_share_of_step": round((msf + msb) / n_prof_steps / ms_step, 4)}
+            # north_star: "rocprof-reported HBM GB/s for the front end": live number here, PMC traffic in profiles/
+            if "mel" in side:
+                nm, msm, wm = side["mel"]
+                mt = None
+                mpath = os.path.join(ROOT, "profiles", "r02_mel_traffic.json")
+                if os.path.isfile(mpath) and args.config == "c2" and B == 64:
+                    with open(mpath) as f:
+                        mt = json.load(f).get("hbm_bytes_per_launch")
+                out["frontend"] = {"bound": "hbm", "kernel": "pa::mel_frontend_kernel (STFT + mel + log + SpecAugment, one launch)",
+                                   "avg_us": round(1e3 * msm / nm, 2), "achieved": round(wm / msm / 1e6, 1), "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round(wm / msm / 1e6 / HBM_PEAK_GBPS, 4),
+                                   "algorithmic_bytes_per_launch": round(wm / nm), "traffic": mt,
+                                   "time_share_of_step": round(msm / n_prof_steps / ms_step, 4)}
             # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
             # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
             # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-            if os.path.isfile(tpath) and args.batch == 64 and args.precision == "bf16":
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_gemm_traffic.json (" + tj["method"] + ")"
+            for tname in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if os.path.isfile(tpath) and args.config == "c2" and B == 64 and args.precision == "bf16":
+                    with open(tpath) as f:
+                        tj = json.load(f)
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tname} (" + tj["method"] + ")"
+                    break
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -205,9 +303,14 @@ def main():
                                          "(all epilogues + weight gradients; 2*M*N*K algorithmic FLOPs per launch)",
                                "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
                                "sampling": f"HIP events around every GEMM launch of 1 timed step in {PROFILE_EVERY} (steps 0, {PROFILE_EVERY}, ...)",
-                               "gemm_time_share_of_step": round(tot_ms / (1e3 * elapsed), 3),
+                               "gemm_time_share_of_step": round(tot_ms / n_prof_steps / ms_step, 4),
                                "per_epilogue": per_kind}
-        if world == 1 and not args.no_cpu_baseline:
+        # multi-GPU: SCALE is measured by the driver when it has an 8-GPU node; what can be said from ONE GPU is a model
+        out["scaling_model"] = {"kind": "MODELLED, not measured", "inputs": "this run's ms_per_step, the reducer's bucket bytes "
+                                "(one bucket per block, launched from the backward), min(N-1, 7) xGMI links x 153 GB/s at 35 % (an ASSUMED RCCL bus efficiency)",
+                                "bucket_MB": {str(k): round(v / 1e6, 2) for k, v in ts.reducer.bucket_bytes().items()},
+                                "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes())}
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -40,24 +40,58 @@ def bucket_layout(named_sizes, depth):
 
 
 class GradReducer:
-    def __init__(self, flat_grads, named_sizes, depth, process_group=None):
+    """comm_dtype "fp32": all-reduce the f32 gradient bucket in place (exact sum).  "bf16": gradient compression for
+    the wire -- the bucket is cast to bf16, all-reduced (RCCL sums in bf16) and added back as f32: half the bytes per
+    link (172 MB instead of 345 MB per step for passt_s), at bf16 rounding of the exchanged sums (not the reference's
+    behaviour: opt-in)."""
+
+    def __init__(self, flat_grads, named_sizes, depth, process_group=None, comm_dtype="fp32"):
+        assert comm_dtype in ("fp32", "bf16")
         self.flat = flat_grads
         self.spans = bucket_layout(named_sizes, depth)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype
         self.pending = []
+
+    def broadcast_(self, flat_params, src=0):
+        """Make every rank's parameters equal to rank ``src``'s (in place)."""
+        if self.world > 1:
+            dist.broadcast(flat_params, src, group=self.group)
 
     def on_block_done(self, i):
         if self.world == 1:
             return
         s, e = self.spans[i]
-        if e > s:
-            # torch.distributed orders the collective after everything already enqueued on the
-            # current stream (the kernels that produced this bucket) and runs it on RCCL's stream
-            self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+        if e <= s:
+            return
+        # torch.distributed orders the collective after everything already enqueued on the current stream (the
+        # kernels that produced this bucket) and runs it on the backend's communication stream
+        if self.comm_dtype == "fp32":
+            self.pending.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                                 None, s, e))
+        else:
+            wire = self.flat[s:e].to(torch.bfloat16)
+            self.pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), wire, s, e))
 
     def wait(self):
-        for w in self.pending:
+        for w, wire, s, e in self.pending:
             w.wait()                      # current stream waits for the communication stream
+            if wire is not None:
+                self.flat[s:e].copy_(wire)
         self.pending = []
+
+    def drain(self):
+        """Yield (start, end) of every launched bucket as soon as its all-reduce is ordered before the current stream."""
+        pending, self.pending = self.pending, []
+        for w, wire, s, e in pending:
+            w.wait()
+            if wire is not None:
+                self.flat[s:e].copy_(wire)
+            yield s, e
+
+    def bucket_bytes(self):
+        """{bucket id: bytes on the wire} in launch order (head, blocks depth-1 .. 0, patch embedding)."""
+        es = 4 if self.comm_dtype == "fp32" else 2
+        order = sorted(self.spans, key=lambda b: (b != max(self.spans), -b))
+        return {b: (self.spans[b][1] - self.spans[b][0]) * es for b in order}

@@ -17,15 +17,44 @@ TORCH_DTYPE = {PA_F32: torch.float32, PA_BF16: torch.bfloat16}
 PA_DTYPE = {torch.float32: PA_F32, torch.bfloat16: PA_BF16}
 
 
+_call_dev = None     # device of the tensors of the C-ABI call being assembled (set by _p, consumed by _stream)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream the call is ordered on: the current stream OF THE DEVICE THE CALL'S TENSORS LIVE ON (not of
+    torch.cuda.current_device(): a model on cuda:1 without set_device must not launch on cuda:0's stream).  Every
+    wrapper passes its tensors through _p() first and _stream() last."""
+    global _call_dev
+    dev, _call_dev = _call_dev, None
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
-def _p(t):
+def _p(t, dtype=None, strided=False):
+    """Raw device pointer of ``t`` for the C ABI, after the checks the kernels rely on: HIP tensor, the expected
+    element type (``dtype``: a torch dtype, PA_F32 / PA_BF16, or None = any), dense rows (contiguous; ``strided`` =
+    only the last dimension must be dense, the leading dimension is passed separately) and the same device as the
+    other tensors of the call.  The kernels reinterpret memory: a wrong dtype or a strided view would read garbage or
+    out of bounds, so this raises instead."""
+    global _call_dev
     if t is None:
         return None
     if not t.is_cuda:
+        _call_dev = None
         raise _lib.PasstAmdError("passt_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    if dtype is not None:
+        want = TORCH_DTYPE.get(dtype, dtype)
+        if t.dtype != want:
+            _call_dev = None
+            raise _lib.PasstAmdError(f"expected a {want} tensor, got {t.dtype}")
+    if not (t.is_contiguous() or (strided and t.dim() >= 1 and (t.shape[-1] <= 1 or t.stride(-1) == 1))):
+        _call_dev = None
+        raise _lib.PasstAmdError(f"expected a {'row-dense' if strided else 'contiguous'} tensor, got strides {tuple(t.stride())} "
+                                 f"for shape {tuple(t.shape)}")
+    if _call_dev is None:
+        _call_dev = t.device
+    elif t.device != _call_dev:
+        d0, _call_dev = _call_dev, None
+        raise _lib.PasstAmdError(f"tensors of one kernel call live on different devices: {d0} and {t.device}")
     return t.data_ptr()
 
 
@@ -35,6 +64,19 @@ GEMM_PROFILE = None
 GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
 GEMM_RESERVED = 0      # pa_gemm_args.reserved (ignored by the product library; probe builds: tools/probe_epilogue.py)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
+
+
+def _timed(kind, work, fn):
+    """Run fn(); when bench.py profiles this step, bracket it with HIP events on the launch stream and file
+    (start, end, work) under `kind` (work = algorithmic FLOPs or bytes of the call)."""
+    if GEMM_PROFILE is None:
+        return fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    r = fn()
+    ev1.record()
+    GEMM_PROFILE.setdefault(kind, []).append((ev0, ev1, work))
+    return r
 
 
 def kpad(dtype):
@@ -50,8 +92,10 @@ def round_up(a, b):
 def mel_frontend(wave, window, bin_mel, twiddle, params: MelParams):
     B, L = wave.shape
     out = torch.empty((B, params.n_mels, params.n_frames), device=wave.device, dtype=torch.float32)
-    check(_lib.load().pa_mel_frontend_fwd(_p(wave), B, L, _p(window), _p(bin_mel), _p(twiddle), _p(out),
-                                          C.byref(params), _stream()), "pa_mel_frontend_fwd")
+    _timed("mel", 4.0 * (B * L + out.numel()),
+           lambda: check(_lib.load().pa_mel_frontend_fwd(_p(wave, torch.float32), B, L, _p(window, torch.float32), _p(bin_mel, torch.float32),
+                                                         _p(twiddle, torch.float32), _p(out), C.byref(params), _stream()),
+                         "pa_mel_frontend_fwd"))
     return out
 
 
@@ -60,7 +104,7 @@ def convert(x_f32, dtype):
     if dtype == PA_F32:
         return x_f32
     out = torch.empty(x_f32.shape, device=x_f32.device, dtype=TORCH_DTYPE[dtype])
-    check(_lib.load().pa_convert_f32(_p(x_f32), _p(out), x_f32.numel(), dtype, _stream()), "pa_convert_f32")
+    check(_lib.load().pa_convert_f32(_p(x_f32, torch.float32), _p(out), x_f32.numel(), dtype, _stream()), "pa_convert_f32")
     return out
 
 
@@ -70,7 +114,7 @@ def transpose(x, out_dtype, ldo=None, out=None):
     ldo = R if ldo is None else ldo
     if out is None:
         out = torch.empty((Cc, ldo), device=x.device, dtype=TORCH_DTYPE[out_dtype])
-    check(_lib.load().pa_transpose(_p(x), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out), out_dtype, ldo,
+    check(_lib.load().pa_transpose(_p(x, None, True), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out), out_dtype, ldo,
                                    _stream()), "pa_transpose")
     return out
 
@@ -102,7 +146,7 @@ def layernorm_fwd(x, gamma, beta, eps, dtype, save_stats=True):
     y = torch.empty((M, D), device=x.device, dtype=TORCH_DTYPE[dtype])
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
-    check(_lib.load().pa_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), dtype, _p(mean), _p(rstd), M, D, eps,
+    check(_lib.load().pa_layernorm_fwd(_p(x, torch.float32), _p(gamma, torch.float32), _p(beta, torch.float32), _p(y), dtype, _p(mean), _p(rstd), M, D, eps,
                                        _stream()), "pa_layernorm_fwd")
     return y, mean, rstd
 
@@ -115,7 +159,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
     dx = torch.empty((M, D), device=x.device, dtype=torch.float32)
     dx_lp = torch.empty((M, D), device=x.device, dtype=dy.dtype) if (want_lp and dtype != PA_F32) else None
     ws = torch.empty(lib.pa_layernorm_bwd_ws_floats(M, D), device=x.device, dtype=torch.float32)
-    check(lib.pa_layernorm_bwd(_p(dy), dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dx_lp),
+    check(lib.pa_layernorm_bwd(_p(dy), dtype, _p(x, torch.float32), _p(gamma, torch.float32), _p(mean, torch.float32), _p(rstd, torch.float32), _p(dres, torch.float32), _p(dx), _p(dx_lp),
                                _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), M, D, _stream()),
           "pa_layernorm_bwd")
     return dx, (dx if dtype == PA_F32 else dx_lp)
@@ -133,23 +177,23 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.N = B.shape[0] if N is None else N
     a.K = A.shape[1] if K is None else K
     a.lda, a.ldb = A.stride(0), B.stride(0)
-    a.A, a.B = _p(A), _p(B)
-    a.bias = _p(bias)
-    a.resid = _p(resid)
+    a.A, a.B = _p(A, dtype, True), _p(B, dtype, True)
+    a.bias = _p(bias, torch.float32)
+    a.resid = _p(resid, torch.float32, True)
     a.ldr = resid.stride(0) if resid is not None else 0
     a.row_mod, a.out_batch_rows, a.out_row_off = row_mod, out_batch_rows, out_row_off
-    a.aux = _p(aux)
+    a.aux = _p(aux, dtype, True)
     a.ldaux = aux.stride(0) if aux is not None else 0
-    a.out_f32 = _p(out_f32)
+    a.out_f32 = _p(out_f32, torch.float32, True)
     a.ldo32 = (out_f32.stride(-2) if out_f32 is not None else 0)
-    a.out_lp = _p(out_lp)
+    a.out_lp = _p(out_lp, dtype, True)
     a.ldolp = out_lp.stride(0) if out_lp is not None else 0
-    a.out_lp2 = _p(out_lp2)
+    a.out_lp2 = _p(out_lp2, dtype, True)
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
     a.tune = GEMM_TUNE
     a.reserved = GEMM_RESERVED
-    a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out), _p(colsum_ws), int(colsum_accumulate)
+    a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
         return
@@ -264,7 +308,7 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     a.dtype, a.epilogue = dtype, EPI_PARTIAL
     a.M, a.N, a.K = N, K, Mtok
     a.lda, a.ldb = dY.stride(0), X.stride(0)
-    a.A, a.B = _p(dY), _p(X)
+    a.A, a.B = _p(dY, dtype, True), _p(X, dtype, True)
     a.out_f32, a.ldo32 = _p(part), K
     a.split_k = S
     a.tune = GEMM_TUNE
@@ -303,10 +347,10 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
         a.dtype, a.epilogue = dtype, EPI_PARTIAL
         a.M, a.N, a.K = N, K, Mtok
         a.lda, a.ldb = dY.stride(0), X.stride(0)
-        a.A, a.B = _p(dY), _p(X)
+        a.A, a.B = _p(dY, dtype, True), _p(X, dtype, True)
         a.out_f32, a.ldo32 = _p(part), K
         a.split_k, a.tune = S, 0
-        r.partial, r.out, r.n, r.splits, r.accumulate = _p(part), _p(out), N * K, S, int(acc)
+        r.partial, r.out, r.n, r.splits, r.accumulate = _p(part), _p(out, torch.float32), N * K, S, int(acc)
         flops += 2.0 * N * K * Mtok
     lib = _lib.load()
     if GEMM_PROFILE is None:
@@ -326,19 +370,19 @@ def colsum(x, out_f32, accumulate=False):
     R, Cc = x.shape
     lib = _lib.load()
     ws = torch.empty(lib.pa_colsum_ws_floats(R, Cc), device=x.device, dtype=torch.float32)
-    check(lib.pa_colsum(_p(x), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out_f32), int(accumulate), _p(ws),
+    check(lib.pa_colsum(_p(x, None, True), PA_DTYPE[x.dtype], R, Cc, x.stride(0), _p(out_f32, torch.float32), int(accumulate), _p(ws),
                         _stream()), "pa_colsum")
 
 
 def rowsum(x, out_f32, ncols=None, accumulate=False):
     R, Cc = x.shape
-    check(_lib.load().pa_rowsum(_p(x), PA_DTYPE[x.dtype], R, Cc if ncols is None else ncols, x.stride(0),
+    check(_lib.load().pa_rowsum(_p(x, None, True), PA_DTYPE[x.dtype], R, Cc if ncols is None else ncols, x.stride(0),
                                 _p(out_f32), int(accumulate), _stream()), "pa_rowsum")
 
 
 def colsum_f32(x, out_f32, accumulate=False):
     R, Cc = x.shape
-    check(_lib.load().pa_colsum_f32(_p(x), R, Cc, x.stride(0), _p(out_f32), int(accumulate), _stream()),
+    check(_lib.load().pa_colsum_f32(_p(x, torch.float32, True), R, Cc, x.stride(0), _p(out_f32, torch.float32), int(accumulate), _stream()),
           "pa_colsum_f32")
 
 
@@ -350,8 +394,9 @@ def attention_fwd(qkv, B, H, N, scale, nq=None):
     D = H * 64
     o = torch.empty((B * nq, D), device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty((B * H * nq,), device=qkv.device, dtype=torch.float32)
-    check(_lib.load().pa_attention_fwd(_p(qkv), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, nq, scale, dtype,
-                                       _stream()), "pa_attention_fwd")
+    _timed("attn_fwd", 4.0 * nq * N * 64 * B * H,
+           lambda: check(_lib.load().pa_attention_fwd(_p(qkv, None, True), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, nq,
+                                                      scale, dtype, _stream()), "pa_attention_fwd"))
     return o, lse
 
 
@@ -365,9 +410,10 @@ def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None):
     if nq < N:
         es = qkv.element_size()
         check(lib.pa_zero2d(_p(dqkv), dqkv.stride(0) * es, H * 64 * es, B * N, _stream()), "pa_zero2d")
-    check(lib.pa_attention_bwd(_p(qkv), qkv.stride(0), _p(o), _p(d_o), o.stride(0), _p(lse), _p(delta),
-                               _p(dqkv), dqkv.stride(0), B, H, N, nq, scale, dtype, _stream()),
-          "pa_attention_bwd")
+    _timed("attn_bwd", 10.0 * nq * N * 64 * B * H,      # five N x N x 64 products: S, dP, dV, dK, dQ
+           lambda: check(lib.pa_attention_bwd(_p(qkv, None, True), qkv.stride(0), _p(o, qkv.dtype, True), _p(d_o, qkv.dtype, True),
+                                              o.stride(0), _p(lse, torch.float32), _p(delta), _p(dqkv), dqkv.stride(0), B, H, N, nq,
+                                              scale, dtype, _stream()), "pa_attention_bwd"))
     return dqkv
 
 
@@ -376,7 +422,7 @@ def gather_rows(x, idx_i32):
     n = idx_i32.numel()
     out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     row_bytes = x.stride(0) * x.element_size()
-    check(_lib.load().pa_gather_rows(_p(x), _p(idx_i32), n, row_bytes, _p(out), _stream()), "pa_gather_rows")
+    check(_lib.load().pa_gather_rows(_p(x), _p(idx_i32, torch.int32), n, row_bytes, _p(out), _stream()), "pa_gather_rows")
     return out
 
 
@@ -386,7 +432,7 @@ def scatter_rows_into_zeros(x_rows, idx_i32, n_rows):
     row_bytes = x_rows.stride(0) * x_rows.element_size()
     lib = _lib.load()
     check(lib.pa_zero2d(_p(out), row_bytes, row_bytes, n_rows, _stream()), "pa_zero2d")
-    check(lib.pa_scatter_rows(_p(x_rows), _p(idx_i32), idx_i32.numel(), row_bytes, _p(out), _stream()), "pa_scatter_rows")
+    check(lib.pa_scatter_rows(_p(x_rows), _p(idx_i32, torch.int32), idx_i32.numel(), row_bytes, _p(out), _stream()), "pa_scatter_rows")
     return out
 
 
@@ -395,7 +441,7 @@ def patch_gather(x, patch_f, patch_t, P, fstride, tstride, dtype):
     B, _, F, T = x.shape
     Np = patch_f.numel()
     cols = torch.empty((B * Np, P * P), device=x.device, dtype=TORCH_DTYPE[dtype])
-    check(_lib.load().pa_patch_gather(_p(x), B, F, T, _p(patch_f), _p(patch_t), Np, P, fstride, tstride, _p(cols),
+    check(_lib.load().pa_patch_gather(_p(x, torch.float32), B, F, T, _p(patch_f, torch.int32), _p(patch_t, torch.int32), Np, P, fstride, tstride, _p(cols),
                                       dtype, _stream()), "pa_patch_gather")
     return cols
 
@@ -447,7 +493,7 @@ def linear_f32_fwd(x, W, b):
     B, D = x.shape
     Cc = W.shape[0]
     y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
-    check(_lib.load().pa_linear_f32_fwd(_p(x), _p(W), _p(b), _p(y), B, Cc, D, _stream()), "pa_linear_f32_fwd")
+    check(_lib.load().pa_linear_f32_fwd(_p(x, torch.float32), _p(W, torch.float32), _p(b, torch.float32), _p(y), B, Cc, D, _stream()), "pa_linear_f32_fwd")
     return y
 
 
@@ -455,7 +501,7 @@ def linear_f32_bwd(dy, x, W, dW, db, accumulate=False):
     B, Cc = dy.shape
     D = x.shape[1]
     dx = torch.empty((B, D), device=x.device, dtype=torch.float32)
-    check(_lib.load().pa_linear_f32_bwd(_p(dy), _p(x), _p(W), _p(dx), _p(dW), _p(db), int(accumulate), B, Cc, D,
+    check(_lib.load().pa_linear_f32_bwd(_p(dy, torch.float32), _p(x, torch.float32), _p(W, torch.float32), _p(dx), _p(dW, torch.float32), _p(db, torch.float32), int(accumulate), B, Cc, D,
                                         _stream()), "pa_linear_f32_bwd")
     return dx
 
@@ -465,7 +511,7 @@ def bce_fwd_bwd(logits, target, grad_scale=1.0):
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
     dlogits = torch.empty_like(logits)
     ws = torch.empty(1 + (B * Cc + 255) // 256, device=logits.device, dtype=torch.float32)
-    check(_lib.load().pa_bce_fwd_bwd(_p(logits), _p(target), B, Cc, grad_scale, _p(loss), _p(dlogits), _p(ws),
+    check(_lib.load().pa_bce_fwd_bwd(_p(logits, torch.float32), _p(target, torch.float32), B, Cc, grad_scale, _p(loss), _p(dlogits), _p(ws),
                                      _stream()), "pa_bce_fwd_bwd")
     return loss, dlogits
 
@@ -476,7 +522,7 @@ def ce_mixup_fwd_bwd(logits, target_i32, target2_i32=None, lam=None, grad_scale=
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
     dlogits = torch.empty_like(logits)
     ws = torch.empty(max(B, 1), device=logits.device, dtype=torch.float32)
-    check(_lib.load().pa_ce_mixup_fwd_bwd(_p(logits), _p(target_i32), _p(target2_i32), _p(lam), B, Cc, grad_scale,
+    check(_lib.load().pa_ce_mixup_fwd_bwd(_p(logits, torch.float32), _p(target_i32, torch.int32), _p(target2_i32, torch.int32), _p(lam, torch.float32), B, Cc, grad_scale,
                                           _p(loss), _p(dlogits), _p(ws), _stream()), "pa_ce_mixup_fwd_bwd")
     return loss, dlogits
 
@@ -485,7 +531,7 @@ def ce_mixup_fwd_bwd(logits, target_i32, target2_i32=None, lam=None, grad_scale=
 def mixup(x, perm_i32, lam):
     B = x.shape[0]
     out = torch.empty_like(x)
-    check(_lib.load().pa_mixup(_p(x), _p(perm_i32), _p(lam), _p(out), B, x[0].numel(), _stream()), "pa_mixup")
+    check(_lib.load().pa_mixup(_p(x, torch.float32), _p(perm_i32, torch.int32), _p(lam, torch.float32), _p(out), B, x[0].numel(), _stream()), "pa_mixup")
     return out
 
 
@@ -494,20 +540,20 @@ def wave_augment(x, L, lengths=None, amp=None, shift=None, partner=None, lam=Non
     B, ldx = x.shape
     out = torch.empty((B, L), device=x.device, dtype=torch.float32)
     ws = torch.empty(B, device=x.device, dtype=torch.float32) if partner is not None else None
-    check(_lib.load().pa_wave_augment(_p(x), B, x.stride(0), _p(lengths), _p(amp), _p(shift), _p(partner), _p(lam), _p(ws),
+    check(_lib.load().pa_wave_augment(_p(x, torch.float32, True), B, x.stride(0), _p(lengths, torch.int32), _p(amp, torch.float32), _p(shift, torch.int32), _p(partner, torch.int32), _p(lam, torch.float32), _p(ws),
                                       _p(out), L, _stream()), "pa_wave_augment")
     return out
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
-    check(_lib.load().pa_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _stream()),
+    check(_lib.load().pa_adamw(_p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32), p.numel(), lr, beta1, beta2, eps, wd, step, _stream()),
           "pa_adamw")
 
 
 def swa_update(avg, p, num_averaged):
     """avg = p if num_averaged == 0 else avg + (p - avg) / (num_averaged + 1), flat f32 buffers."""
-    check(_lib.load().pa_swa_update(_p(avg), _p(p), p.numel(), int(num_averaged), _stream()), "pa_swa_update")
+    check(_lib.load().pa_swa_update(_p(avg, torch.float32), _p(p, torch.float32), p.numel(), int(num_averaged), _stream()), "pa_swa_update")
 
 
 def sgd(p, g, lr):
-    check(_lib.load().pa_sgd(_p(p), _p(g), p.numel(), lr, _stream()), "pa_sgd")
+    check(_lib.load().pa_sgd(_p(p, torch.float32), _p(g, torch.float32), p.numel(), lr, _stream()), "pa_sgd")

@@ -232,6 +232,9 @@ def passt_forward(model, x, save):
     dt = _precision(model)
     st = model._staged
     x = x.contiguous().float()
+    if x.dim() != 4 or x.shape[1] != 1:
+        raise ValueError(f"PaSST expects a (B, 1, n_mels, frames) spectrogram, got {tuple(x.shape)} "
+                         "(in_chans = 1 in every reference arch, models/passt.py:961)")
     B, Cin, F, T = x.shape
     P, (fs, ts) = model.patch_embed.patch_size[0], model.patch_embed.stride
     if not (F == model.patch_embed.img_size[0] and T == model.patch_embed.img_size[1]):
@@ -436,6 +439,9 @@ class _PasstFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
+        if x.requires_grad:
+            raise NotImplementedError("passt_amd.PaSST does not produce a gradient w.r.t. its input spectrogram (the reference's "
+                                      "training never asks for one); detach() the input")
         logits, feat, c = passt_forward(model, x, save=True)
         ctx.model, ctx.c = model, c
         return logits, feat
@@ -443,13 +449,17 @@ class _PasstFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, dfeat):
         model, c = ctx.model, ctx.c
-        names = model._grad_names
-        flat = torch.empty(model._n_grad_elems, device=dlogits.device, dtype=torch.float32)
+        if c is None:
+            raise RuntimeError("passt_amd.PaSST: the saved activations of this forward were already consumed by a backward "
+                               "pass (retain_graph / double backward are not supported: run the forward again)")
+        # gradient buffers for EVERY parameter the backward writes (all but head_dist.*): the kernel sequence produces
+        # them all; parameters with requires_grad=False are simply not handed back to autograd (frozen backbone, ...)
+        named = [(n, p) for n, p in model.named_parameters() if not n.startswith("head_dist.")]
+        flat = torch.empty(sum(p.numel() for _, p in named), device=dlogits.device, dtype=torch.float32)
         grads, off = {}, 0
-        for n, p in model.named_parameters():
-            if n in names:
-                grads[n] = flat[off:off + p.numel()].view(p.shape)
-                off += p.numel()
+        for n, p in named:
+            grads[n] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
         # a fresh flat buffer per backward: autograd may keep (not copy) the views as .grad
         passt_backward(model, c, dlogits.contiguous(), None if dfeat is None else dfeat.contiguous(), grads)
         ctx.c = None
@@ -631,9 +641,16 @@ def get_model(arch="passt_s_kd_p16_128_ap486", pretrained=True, n_classes=527, i
     ``load_state_dict`` a reference checkpoint (identical keys)."""
     if arch not in _ARCHS:
         raise RuntimeError(f"Unknown model {arch}")
+    ckpt = None
     if pretrained:
-        raise RuntimeError("pretrained=True requires downloading the reference checkpoint (no network here); "
-                           "use pretrained=False and model.load_state_dict(torch.load(<reference .pt>))")
+        # the reference downloads <arch>.pt from its GitHub release (models/helpers/vit_helpers.py:85-91); this build is
+        # offline, so the checkpoint must already be on disk: PASST_AMD_CHECKPOINT_DIR/<arch>.pt (same file, same keys)
+        ckpt_dir = os.environ.get("PASST_AMD_CHECKPOINT_DIR")
+        ckpt = os.path.join(ckpt_dir, arch + ".pt") if ckpt_dir else None
+        if not ckpt or not os.path.isfile(ckpt):
+            raise RuntimeError(f"pretrained=True: no local checkpoint for {arch} (no network here to download the reference's "
+                               f"release file).  Put {arch}.pt into a directory and set PASST_AMD_CHECKPOINT_DIR to it, or use "
+                               "pretrained=False and model.load_state_dict(torch.load(<reference .pt>))")
     depth, want = _ARCHS[arch]
     stride = (fstride, tstride)
     if want is not None and stride != want:
@@ -641,6 +658,15 @@ def get_model(arch="passt_s_kd_p16_128_ap486", pretrained=True, n_classes=527, i
     model = PaSST(u_patchout=u_patchout, s_patchout_t=s_patchout_t, s_patchout_f=s_patchout_f,
                   img_size=(input_fdim, input_tdim), patch_size=16, stride=stride, in_chans=in_channels,
                   num_classes=n_classes, embed_dim=768, depth=depth, num_heads=12, distilled=True)
+    if ckpt is not None:
+        sd = torch.load(ckpt, map_location="cpu")
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        if n_classes != 527:       # the reference drops the classifier of the pre-trained net when the label set differs
+            sd = {k: v for k, v in sd.items() if not k.startswith(("head.1.", "head_dist."))}
+            missing = model.load_state_dict(sd, strict=False)
+            assert all(k.startswith(("head.1.", "head_dist.")) for k in missing.missing_keys), missing
+        else:
+            model.load_state_dict(sd, strict=True)
     model = fix_embedding_layer(model)
     model = lighten_model(model)
     return model
@@ -675,8 +701,8 @@ try:  # the reference exposes these through a sacred/ba3l ingredient (models/pas
 
     model_ing = Ingredient("passt")
     model_ing.add_config(instance_cmd="get_model")
-    model_ing.command(fix_embedding_layer)
-    model_ing.command(lighten_model)
+    fix_embedding_layer = model_ing.command(fix_embedding_layer)
+    lighten_model = model_ing.command(lighten_model)
     get_model = model_ing.command(get_model)
     get_ensemble_model = model_ing.command(get_ensemble_model)
 except Exception:  # ba3l not installed: plain functions

@@ -17,13 +17,18 @@ from .passt import passt_backward, passt_forward
 
 class TrainStep:
     def __init__(self, net, mel=None, lr=2e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, optimizer="adamw",
-                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce"):
+                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce", comm_dtype="fp32"):
         self.net, self.mel = net, mel
         self.lr, self.wd, self.betas, self.eps, self.optimizer = lr, weight_decay, betas, eps, optimizer
         self.mixup_alpha, self.use_mixup = mixup_alpha, use_mixup
         assert loss in ("bce", "ce")      # bce: ex_audioset.py:181-186 ; ce: ex_esc50.py:159-165 (class-index targets)
         self.loss = loss
         dev = next(net.parameters()).device
+        frozen = [n for n, p in net.named_parameters() if not p.requires_grad and not n.startswith("head_dist.")]
+        if frozen:
+            raise NotImplementedError("TrainStep updates every PaSST parameter through one flat buffer (the reference trains all of "
+                                      f"them, ex_audioset.py:104-109); frozen parameters are not supported here: {frozen[:3]} ... "
+                                      "use the autograd path (net(x); loss.backward()) with your own optimizer instead")
         names = net._grad_names
         self.named = [(n, p) for n, p in net.named_parameters() if n in names]
         total = sum(p.numel() for _, p in self.named)
@@ -40,10 +45,21 @@ class TrainStep:
             off += k
         self.m = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
         self.v = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
-        self.reducer = GradReducer(self.flat_g, [(n, p.numel()) for n, p in self.named], len(net.blocks), process_group)
+        self.reducer = GradReducer(self.flat_g, [(n, p.numel()) for n, p in self.named], len(net.blocks), process_group,
+                                   comm_dtype=comm_dtype)
+        # identical replicas: rank 0's parameters everywhere (what Lightning's DDP wrapper does at construction,
+        # ex_audioset.py:488-489); a caller that seeded per rank or loaded different state must not train diverging copies
+        self.reducer.broadcast_(self.flat_p)
         self.t = 0
         self.base_lr = lr
         net.mark_params_updated()
+
+    def _optimizer(self, s, e):
+        if self.optimizer == "adamw":
+            ops.adamw(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, self.t)
+        else:
+            ops.sgd(self.flat_p[s:e], self.flat_g[s:e], self.lr)
 
     def set_lr_factor(self, factor):
         """Per-epoch LR schedule (ex_audioset.py:86-101): lr = base_lr * factor, e.g. from
@@ -58,8 +74,11 @@ class TrainStep:
         if self.mel is not None:
             if x.dim() == 3:
                 x = x.reshape(-1, x.shape[2])                                   # mel_forward, :142-145
-            x = self.mel(x).unsqueeze(1)
-        y = target
+            x = self.mel(x.contiguous().float()).unsqueeze(1)
+        else:
+            x = x.contiguous().float()
+        # the kernels reinterpret raw memory: hand them dense f32 targets (BCE) / integer class ids (CE)
+        y = target.contiguous() if self.loss == "ce" else target.to(torch.float32).contiguous()
         if self.use_mixup:
             B = x.shape[0]
             perm = torch.randperm(B)                                            # helpers/mixup.py:6
@@ -81,12 +100,14 @@ class TrainStep:
             else:
                 loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, grad_scale=gs)
         passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self.reducer.on_block_done)
-        self.reducer.wait()
         self.t += 1
-        if self.optimizer == "adamw":
-            ops.adamw(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.wd, self.t)
+        if self.reducer.world == 1:
+            self._optimizer(0, self.flat_p.numel())
         else:
-            ops.sgd(self.flat_p, self.flat_g, self.lr)
+            # one optimizer launch per all-reduce bucket, in the order the buckets were launched: the update of bucket k runs
+            # while buckets k+1.. are still on the wire, so the LAST bucket (block 0 + patch embedding, released only when
+            # the backward ends) is covered by ~0.4 ms of optimizer work instead of being exposed in front of one big launch
+            for s_, e_ in self.reducer.drain():
+                self._optimizer(s_, e_)
         net.mark_params_updated()
         return loss

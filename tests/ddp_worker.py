@@ -1,0 +1,94 @@
+"""Worker of tests/test_gpu_ddp.py: one process = one data-parallel rank of the REAL training step (passt_amd.train.TrainStep
+on the HIP kernels, passt_backward's per-block bucket callbacks, per-bucket optimizer launches) -- every rank on the single
+GPU of the test box, transport "gloo" on device tensors (RCCL refuses two ranks on one device; the reducer code path is
+the same, only the backend string differs).
+
+    python tests/ddp_worker.py --out ref.pt                       single process, batch = both halves concatenated
+    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/ddp_worker.py --out dp.pt [--comm-dtype bf16]
+"""
+import argparse
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import passt_amd  # noqa: E402
+from oracle import detgen  # noqa: E402
+from passt_amd.train import TrainStep  # noqa: E402
+from tests.golden import make_golden as G  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--comm-dtype", default="fp32")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--overlap-wgrad", action="store_true")
+    ap.add_argument("--optimizer", default="sgd")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = dict(G.CASES["model_small_train"], B=8, seed=333)
+    cfg = case["cfg"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = passt_amd.PaSST(u_patchout=cfg["u_patchout"], s_patchout_t=cfg["s_patchout_t"], s_patchout_f=cfg["s_patchout_f"],
+                              img_size=cfg["img_size"], patch_size=cfg["patch"], stride=cfg["stride"],
+                              num_classes=cfg["num_classes"], embed_dim=cfg["embed_dim"], depth=cfg["depth"],
+                              num_heads=cfg["num_heads"], distilled=True)
+    sd = detgen.passt_state_dict(cfg, case["seed"])
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    net = net.to(dev).train()
+    net.precision = "fp32"
+    net.overlap_wgrad = args.overlap_wgrad
+    if rank > 0:                        # a replica that was initialised differently: TrainStep must overwrite it with rank 0's
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.25)
+    x, y = G.model_inputs(case)         # the global batch of 8 clips; rank r takes rows [4r, 4r+4)
+    xg, yg = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    if world > 1:
+        per = x.shape[0] // world
+        xg, yg = xg[rank * per:(rank + 1) * per].contiguous(), yg[rank * per:(rank + 1) * per].contiguous()
+    ts = TrainStep(net, None, lr=1e-3 if args.optimizer == "adamw" else 0.05, weight_decay=1e-2, use_mixup=False,
+                   comm_dtype=args.comm_dtype, optimizer=args.optimizer)
+    init = ts.flat_p.clone()            # after the constructor's broadcast: rank 0's weights on every rank
+    losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(args.steps):
+            torch.manual_seed(900 + step)   # the SAME patchout draws on every rank and in the single-process run
+            np.random.seed(900 + step)
+            losses.append(float(ts.step(xg, yg).item()))
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        # all ranks must hold the same parameters after the steps
+        mine = ts.flat_p.clone()
+        ref0 = ts.flat_p.clone()
+        dist.broadcast(ref0, 0)
+        same = bool(torch.equal(mine, ref0))
+        flags = [None] * world
+        dist.all_gather_object(flags, (same, losses))
+    else:
+        flags = [(True, losses)]
+    if rank == 0:
+        torch.save({"params": ts.flat_p.cpu(), "init": init.cpu(), "flags": flags, "world": world}, args.out)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,18 @@ CASES = {
     # BASELINE config #1 at full width/depth: passt_s_swa_p16_128_ap476, eval, no patchout
     "model_passt_s_eval": dict(cfg=O.make_cfg(), B=1, T=998, training=False, seed=14),
 }
+# Full-size cases (r02): the headline training configuration at real depth (prefix-only tail and batched weight gradients
+# active), BASELINE config #4 (1024/24/16, unstructured patchout 400) and the 20 s / 30 s inference archs.  Gradients
+# of these are stored COMPACT (1024 evenly spaced entries + L2 norm per tensor): the full sets would be 0.3-1.2 GB.
+BIG_CASES = {
+    "model_passt_s_train_full": dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=2, T=998, training=True,
+                                     seed=15, torch_seed=4321, compact=True),
+    "model_vitl_u400_train": dict(cfg=O.make_cfg(embed_dim=1024, depth=24, num_heads=16, u_patchout=400), B=1, T=998,
+                                  training=True, seed=16, torch_seed=99, compact=True),
+    # passt_s_f128_20sec_p16_s10_ap474 / passt_s_f128_30sec_p16_s10_ap473 (models/passt.py:990-1003): N = 2390 / 3590
+    "model_passt_s_20s_eval": dict(cfg=O.make_cfg(img_size=(128, 2000)), B=1, T=2000, training=False, seed=17),
+    "model_passt_s_30s_eval": dict(cfg=O.make_cfg(img_size=(128, 3000)), B=1, T=3000, training=False, seed=18),
+}
 FRONTEND_CASES = {
     "frontend_eval": dict(B=2, L=32000, training=False, seed=21,
                           kw=dict(fmin_aug_range=10, fmax_aug_range=2000)),
@@ -64,11 +76,14 @@ def frontend_inputs(case):
     return (0.1 * w * (1.0 + 0.5 * np.sin(n / 977.0)) + chirp).astype(np.float32)
 
 
-def subsample(g):
-    """Full tensor for small ones; every 7th element + L2 norm for large ones."""
+def subsample(g, compact=False):
+    """Full tensor for small ones; every 7th element (compact: 1024 evenly spaced elements) + L2 norm for large ones."""
     flat = np.ascontiguousarray(g).reshape(-1)
     if flat.size <= 4096:
         return flat.copy(), float(np.linalg.norm(flat.astype(np.float64)))
+    if compact:
+        idx = np.linspace(0, flat.size - 1, 1024).astype(np.int64)
+        return flat[idx].copy(), float(np.linalg.norm(flat.astype(np.float64)))
     return flat[::7].copy(), float(np.linalg.norm(flat.astype(np.float64)))
 
 
@@ -90,7 +105,7 @@ def gen_model_case(name, case):
             if p.grad is None:
                 out["gradnone." + k] = np.zeros(0, np.float32)
             else:
-                s, nrm = subsample(p.grad.numpy())
+                s, nrm = subsample(p.grad.numpy(), case.get("compact", False))
                 out["grad." + k] = s
                 out["gradnorm." + k] = np.float64(nrm)
         # replay the index draws (same seed, same call order) so the fixture holds them
@@ -200,7 +215,11 @@ def gen_rng_kat():
 
 if __name__ == "__main__":
     assert ref_import.reference_available(), "needs /root/reference"
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(32, os.cpu_count()))
+    if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the full-size cases (minutes of CPU time)
+        for n, c in BIG_CASES.items():
+            gen_model_case(n, c)
+        sys.exit(0)
     for n, c in CASES.items():
         gen_model_case(n, c)
     for n, c in FRONTEND_CASES.items():

@@ -59,7 +59,27 @@ def _worker(rank, world, port, q):
         seen.append(len(red.pending))
     red.wait()
     expect = torch.arange(total, dtype=torch.float32) * sum(r + 1 for r in range(world))
-    q.put((rank, bool(torch.equal(flat, expect)), seen, red.world))
+    ok = bool(torch.equal(flat, expect))
+    # drain(): buckets come back in launch order and cover the whole buffer exactly once (TrainStep updates per bucket)
+    flat2 = torch.ones(total) * (rank + 1)
+    red2 = GradReducer(flat2, sizes, 3)
+    for blk in (3, 2, 1, 0, -1):
+        red2.on_block_done(blk)
+    spans = list(red2.drain())
+    ok = ok and spans == [red2.spans[b] for b in (3, 2, 1, 0, -1)] and sorted(spans)[0][0] == 0 and \
+        sum(e - s for s, e in spans) == total and bool(torch.equal(flat2, torch.full((total,), 3.0)))
+    # bf16 wire format: sums of values exactly representable in bf16 stay exact
+    flat3 = torch.full((total,), 0.5 * (rank + 1))
+    red3 = GradReducer(flat3, sizes, 3, comm_dtype="bf16")
+    for blk in (3, 2, 1, 0, -1):
+        red3.on_block_done(blk)
+    red3.wait()
+    ok = ok and bool(torch.equal(flat3, torch.full((total,), 1.5))) and sum(red3.bucket_bytes().values()) == 2 * total
+    # broadcast_: every rank ends with rank 0's parameters
+    pbuf = torch.full((16,), float(rank + 7))
+    red.broadcast_(pbuf)
+    ok = ok and bool(torch.equal(pbuf, torch.full((16,), 7.0)))
+    q.put((rank, ok, seen, red.world))
     dist.destroy_process_group()
 
 

@@ -21,6 +21,9 @@ from tests.golden import make_golden as G  # noqa: E402
 
 DEV = "cuda"
 _METRICS = {}
+# bf16 (throughput mode) bounds, relative to the largest reference entry.  Measured on MI355X: logits / features 2-4e-3,
+# gradients 5-7e-3 (profiles/r0*_model_parity_metrics.json); the bounds leave ~4x, so a 5x numerical regression fails.
+BF16_LOGITS, BF16_GRADS = 1.5e-2, 2.5e-2
 
 
 def record(name, **kw):
@@ -59,7 +62,7 @@ def test_model_vs_golden(golden_dir, name, precision):
     m.train(case["training"])
     x, y = G.model_inputs(case)
     xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
-    lim = 1e-3 if precision == "fp32" else 4e-2
+    lim = 1e-3 if precision == "fp32" else BF16_LOGITS
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         if case["training"]:
@@ -83,7 +86,7 @@ def test_model_vs_golden(golden_dir, name, precision):
             got, _ = G.subsample(p.grad.detach().cpu().numpy())
             e = rel(got, gold["grad." + k])
             worst = max(worst, e)
-            assert e < (1e-3 if precision == "fp32" else 6e-2), (k, e)
+            assert e < (1e-3 if precision == "fp32" else BF16_GRADS), (k, e)
         metrics["worst_grad"] = worst
     record(f"{name}[{precision}]", **metrics)
 
@@ -231,7 +234,7 @@ def test_baseline_config_shapes_vs_oracle(name, precision):
         torch.manual_seed(case["torch_seed"])
         lg, fg = m(xg)
         torch.nn.functional.binary_cross_entropy_with_logits(lg, yg, reduction="none").mean().backward()
-    lim = 1e-3 if precision == "fp32" else 4e-2
+    lim = 1e-3 if precision == "fp32" else BF16_LOGITS
     e_l, e_f = rel(lg.detach().cpu(), lo.detach()), rel(fg.detach().cpu(), fo.detach())
     assert e_l < lim and e_f < lim, (e_l, e_f)
     worst = 0.0
@@ -240,7 +243,7 @@ def test_baseline_config_shapes_vs_oracle(name, precision):
             continue
         e = rel(p.grad.cpu(), sd[k].grad)
         worst = max(worst, e)
-        assert e < (1e-3 if precision == "fp32" else 8e-2), (k, e)
+        assert e < (1e-3 if precision == "fp32" else BF16_GRADS), (k, e)
     record(f"{name}[{precision}]", logits=e_l, features=e_f, worst_grad=worst)
 
 
@@ -296,3 +299,137 @@ def test_swa_matches_reference_update_rule():
     # the trained module itself is untouched
     for (name, p), s in zip(ts.named, snap):
         assert torch.equal(p.detach().double().cpu(), s), name
+
+
+# ---- r02: full-size goldens produced by the REAL reference (tests/golden/make_golden.py big) ---------------------------
+@pytest.mark.parametrize("name", list(G.BIG_CASES))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_model_vs_golden(golden_dir, name, precision):
+    """passt_s at real depth in train mode (474 tokens: prefix-only tail + batched weight gradients active), BASELINE
+    config #4 (1024/24/16, u_patchout=400, 790 tokens) and the 20 s / 30 s inference archs (2390 / 3590 tokens)."""
+    case = G.BIG_CASES[name]
+    gold = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    m = build(case, precision)
+    m.train(case["training"])
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if case["training"]:
+            torch.manual_seed(case["torch_seed"])
+            logits, feat = m(xg)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, yg, reduction="none").mean()
+            loss.backward()
+        else:
+            with torch.no_grad():
+                logits, feat = m(xg)
+    e_l, e_f = rel(logits.detach().cpu(), gold["logits"]), rel(feat.detach().cpu(), gold["features"])
+    metrics = dict(logits=e_l, features=e_f)
+    lim = 1e-3 if precision == "fp32" else BF16_LOGITS
+    assert e_l < lim and e_f < lim, (e_l, e_f)
+    if case["training"]:
+        assert abs(loss.item() - float(gold["loss"])) < (1e-5 if precision == "fp32" else 2e-3)
+        worst, worst_norm = 0.0, 0.0
+        for k, p in m.named_parameters():
+            if "gradnone." + k in gold:
+                assert p.grad is None, k
+                continue
+            g = p.grad.detach().cpu().numpy()
+            got, nrm = G.subsample(g, compact=True)
+            e = rel(got, gold["grad." + k])
+            en = abs(nrm - float(gold["gradnorm." + k])) / (float(gold["gradnorm." + k]) + 1e-30)
+            worst, worst_norm = max(worst, e), max(worst_norm, en)
+            # the sampled entries are judged against the largest SAMPLED reference entry; the L2 norm covers the rest
+            assert e < (1e-3 if precision == "fp32" else BF16_GRADS), (k, e)
+            assert en < (1e-3 if precision == "fp32" else BF16_GRADS), (k, en)
+        metrics.update(worst_grad=worst, worst_grad_norm=worst_norm)
+    record(f"{name}[{precision}]", **metrics)
+
+
+def test_ensemble_and_other_strides_eval():
+    """get_ensemble_model (models/passt.py:1021-1045): mean of the member logits; members with stride 10 and stride 14
+    (different patch grids: 12x99 and 9x71) each against the oracle."""
+    archs = [("passt_s_swa_p16_128_ap476", 10, 10), ("passt_s_swa_p16_s14_128_ap471", 14, 14)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ens = passt_amd.get_ensemble_model(archs)
+    x = torch.from_numpy(detgen.uniform(61, "x", (2, 1, 128, 998), -1.5, 1.5))
+    outs = []
+    for i, (m, (_, fs, ts)) in enumerate(zip(ens.models, archs)):
+        cfg = O.make_cfg(stride=(fs, ts))
+        sd = detgen.passt_state_dict(cfg, 600 + i)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lo, _ = O.passt_forward(O.to_torch(sd), x, cfg, training=False)
+        outs.append(lo)
+    ens = ens.to(DEV).eval()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, b = ens(x.to(DEV))
+        singles = [m(x.to(DEV))[0] for m in ens.models]
+    assert torch.equal(a, b)
+    assert rel(a.cpu(), ((singles[0] + singles[1]) / 2).cpu()) < 1e-6
+    for i in range(2):
+        assert rel(singles[i].cpu(), outs[i]) < 1e-3, i
+    record("ensemble_eval[fp32]", member0=rel(singles[0].cpu(), outs[0]), member1=rel(singles[1].cpu(), outs[1]))
+
+
+@pytest.mark.parametrize("T", [437, 998, 1203])
+def test_variable_length_eval(T):
+    """ex_fsd50k.py:53-56 (variable_eval): batch 1, clips of any length.  Shorter than the model's 998 frames: the time
+    positional embedding is cropped from offset 0 (models/passt.py:513-522); longer: warning + cut (:524-526)."""
+    cfg = O.make_cfg(depth=2)
+    sd = detgen.passt_state_dict(cfg, 77)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = passt_amd.PaSST(img_size=(128, 998), stride=10, embed_dim=768, depth=2, num_heads=12, distilled=True)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(detgen.uniform(78, "x", (1, 1, 128, T), -1.5, 1.5))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lo, fo = O.passt_forward(O.to_torch(sd), x, cfg, training=False)
+        lg, fg = m(x.to(DEV))
+    assert rel(lg.cpu(), lo) < 1e-3 and rel(fg.cpu(), fo) < 1e-3
+
+
+def test_frozen_parameters_and_input_checks():
+    """Reference behaviour with a frozen backbone: autograd hands gradients to the trainable parameters only."""
+    case = dict(G.CASES["model_small_train"], seed=321)
+    m = build(case, "fp32").train()
+    for n, p in m.named_parameters():
+        p.requires_grad_(n.startswith(("head.", "norm.")))
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    m2 = build(case, "fp32").train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(3)
+        lg, _ = m(xg)
+        torch.nn.functional.binary_cross_entropy_with_logits(lg, yg).backward()
+        torch.manual_seed(3)
+        lg2, _ = m2(xg)
+        torch.nn.functional.binary_cross_entropy_with_logits(lg2, yg).backward()
+    for (n, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if p.requires_grad:
+            assert torch.equal(p.grad, p2.grad), n
+        else:
+            assert p.grad is None, n
+    with pytest.raises(NotImplementedError):
+        m2(xg.clone().requires_grad_(True))
+    with pytest.raises(ValueError):
+        m2(torch.zeros(2, 3, 128, 250, device=DEV))
+    # the C-ABI wrappers refuse what the kernels would misread: wrong dtype, strided views, mixed devices
+    from passt_amd import ops
+    from passt_amd._lib import PasstAmdError
+    perm = torch.tensor([1, 0, 2], device=DEV, dtype=torch.int32)
+    lam = torch.ones(3, device=DEV)
+    with pytest.raises(PasstAmdError):
+        ops.mixup(yg.double(), perm, lam)
+    with pytest.raises(PasstAmdError):
+        ops.mixup(yg, perm.long(), lam)
+    with pytest.raises(PasstAmdError):
+        ops.mixup(yg.t().contiguous().t(), perm, lam)
+    out = ops.mixup(yg, perm, lam)           # still works after the rejected calls
+    assert torch.equal(out, yg)

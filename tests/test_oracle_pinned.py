@@ -56,6 +56,29 @@ def test_model_oracle_vs_golden(golden_dir, name):
             assert abs(got_nrm - nrm) <= 1e-4 * nrm + 1e-9, k
 
 
+@pytest.mark.parametrize("name", list(G.BIG_CASES))
+def test_full_size_oracle_vs_golden(golden_dir, name):
+    """The oracle at the sizes the headline runs at: passt_s depth 12, 474 tokens, train-mode fwd+bwd (gradients stored
+    compact: 1024 samples + L2 norm per tensor), BASELINE config #4 (1024/24/16, u_patchout=400) and the 20 s / 30 s
+    inference archs (2390 / 3590 tokens)."""
+    case = G.BIG_CASES[name]
+    gold = _load(golden_dir, name)
+    sd, logits, feat, loss = _oracle_model_case(case)
+    np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], atol=5e-5, rtol=2e-4)
+    np.testing.assert_allclose(feat.detach().numpy(), gold["features"], atol=5e-5, rtol=2e-4)
+    if case["training"]:
+        assert abs(loss.item() - float(gold["loss"])) < 1e-6
+        for k, p in sd.items():
+            if "gradnone." + k in gold:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            ref, nrm = gold["grad." + k], float(gold["gradnorm." + k])
+            got, got_nrm = G.subsample(p.grad.numpy(), compact=True)
+            scale = max(float(np.abs(ref).max()), 1e-8)
+            assert np.abs(got - ref).max() <= 5e-4 * scale + 1e-9, k
+            assert abs(got_nrm - nrm) <= 2e-4 * nrm + 1e-9, k
+
+
 def test_patchout_indices_bit_exact(golden_dir):
     """patchout indices must be bit-exact (north_star): replay the torch CPU RNG draws."""
     for name, case in G.CASES.items():

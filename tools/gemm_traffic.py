@@ -39,3 +39,15 @@ summary = {"kernel_family": "pa::gemm_nt_* + pa::gemm_tn_* (bf16)", "launches": 
                      "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported; KB -> bytes",
            "per_kernel": res}
 print(json.dumps(summary, indent=1))
+# the front-end kernel, for bench.py's `frontend.traffic` (north_star: rocprof-reported HBM bytes of the front end)
+if len(sys.argv) > 3:
+    mf = [v for k, v in fetch.items() if "mel_frontend" in k]
+    mw = [v for k, v in write.items() if "mel_frontend" in k]
+    if mf and mw:
+        f, w = mf[0], mw[0]
+        rd, wr = 2 * sum(f) / len(f) * 1e3, sum(w) / len(w) * 1e3
+        with open(sys.argv[3], "w") as fh:
+            json.dump({"kernel": "pa::mel_frontend_kernel", "launches": len(f), "read_bytes_per_launch": round(rd),
+                       "write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr),
+                       "algorithmic_bytes_per_launch": 64 * (320000 + 128 * 1000) * 4,
+                       "method": summary["method"]}, fh, indent=1)
