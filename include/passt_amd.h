@@ -37,7 +37,8 @@ enum {
     PA_OK = 0,
     PA_EINVAL = -1,   /* bad argument (null pointer, negative size, ...) */
     PA_EUNSUPPORTED = -2, /* shape/dtype outside what the kernels cover */
-    PA_ELAUNCH = -3   /* hipLaunch failed; see pa_last_hip_error() */
+    PA_ELAUNCH = -3,  /* hipLaunch failed; see pa_last_hip_error() */
+    PA_ECOMM = -4     /* RCCL missing or a collective call failed; see pa_comm_last_error() */
 };
 
 int pa_abi_version(void);
@@ -311,6 +312,25 @@ int pa_sgd(float* p, const float* g, int64_t n, float lr, void* stream);
 /* Stochastic weight averaging step on flat buffers (helpers/swa_callback.py:246-268, update_parameters + avg_fn):
  * num_averaged == 0: avg = p;  else avg += (p - avg) / (num_averaged + 1).  The caller increments the count. */
 int pa_swa_update(float* avg, const float* p, int64_t n, int num_averaged, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel exchange step: gradient all-reduce over RCCL / xGMI, one communicator per process (= per GPU).
+ * Replaces Lightning's DDP plugin (ex_audioset.py:488-489 -> torch DDP: NCCL all-reduce of gradient buckets from
+ * autograd hooks; mean of the per-rank gradients).  Here the caller owns the buckets: contiguous slices of its flat
+ * gradient buffer, reduced IN PLACE (sum; the 1/world factor is folded into the loss gradient), launched as soon as a
+ * block's gradients are complete (passt_amd.ddp.GradReducer drives it from the backward's callbacks).
+ * RCCL is loaded at run time (dlopen); a process that never calls these functions does not need it.
+ * ------------------------------------------------------------------------------------------ */
+#define PA_COMM_ID_BYTES 128
+/* rank 0: 128 opaque bytes (an ncclUniqueId) to hand to every rank out of band (file, socket, torch store ...) */
+int pa_comm_unique_id(void* id_out);
+/* every rank, after selecting its device (hipSetDevice / torch.cuda.set_device): blocks until all `world` ranks joined */
+int pa_comm_init(const void* id, int rank, int world, void** comm_out);
+/* buf[count] (dtype PA_F32 or PA_BF16) <- sum over ranks, in place, asynchronous and ordered on `stream` */
+int pa_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int pa_comm_destroy(void* comm);
+/* text of the last PA_ECOMM on the calling thread */
+const char* pa_comm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -83,7 +83,13 @@ SIGNATURES = {
     "pa_sgd": (i32, [vp, vp, i64, f32, vp]),
     "pa_swa_update": (i32, [vp, vp, i64, i32, vp]),
     "pa_wave_augment": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "pa_comm_unique_id": (i32, [vp]),
+    "pa_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "pa_allreduce_bucket": (i32, [vp, vp, i64, i32, vp]),
+    "pa_comm_destroy": (i32, [vp]),
+    "pa_comm_last_error": (C.c_char_p, []),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -117,4 +123,6 @@ def check(rc, what=""):
         msg = lib.pa_error_string(rc).decode()
         if rc == -3:
             msg += ": " + lib.pa_last_hip_error().decode()
+        if rc == -4:
+            msg += ": " + lib.pa_comm_last_error().decode()
         raise PasstAmdError(f"{what} failed: {msg} (code {rc})")

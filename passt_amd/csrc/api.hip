@@ -19,6 +19,7 @@ extern "C" const char* pa_error_string(int code) {
         case PA_EINVAL: return "invalid argument";
         case PA_EUNSUPPORTED: return "unsupported shape or dtype";
         case PA_ELAUNCH: return "kernel launch failed (see pa_last_hip_error)";
+        case PA_ECOMM: return "RCCL unavailable or collective failed (see pa_comm_last_error)";
     }
     return "unknown error code";
 }

@@ -10,8 +10,18 @@
 //   :78     log(mel + 1e-5), :80-82 SpecAugment masks, :84 (x+4.5)/5 -> epilogue
 // HBM traffic = read the waveform once (+6% halo) and write the mel tile once.
 //
-// Workgroup = 8 waves = 32 consecutive frames of one clip (4 frames per wave); the 32-frame output
+// Workgroup = 4 waves = 32 consecutive frames of one clip (8 frames per wave); the 32-frame output
 // tile is transposed through LDS so every mel row is written as 128 contiguous bytes.
+//
+// r02 (profiles/r02_mel_variants.txt): the FFT is NOT what the kernel waits for.  With 8 waves and ~100 KiB of LDS per
+// workgroup only one workgroup fitted a CU, and each one spent ~3/4 of its life in its un-overlapped prologue (a
+// 21-iteration loop of dependent scalar loads staging the waveform span) and epilogue.  Now: 4 waves per workgroup and
+// 79 KiB => two workgroups per CU (one stages while the other transforms), the span is staged with 16-byte loads that
+// are all in flight together, and the sparse mel product reads ONE precomputed contribution per bin (P*u / P*(1-u)
+// stored instead of P) in loops unrolled four-fold with independent accumulators.  (Rejected: LDS float atomics for a
+// bin-parallel mel product -- 2.4x slower than the band loops, 402 vs 164 us: same-address ds_add_f32 serialise.)
+#include <algorithm>
+
 #include "pa_common.h"
 
 namespace pa {
@@ -19,7 +29,7 @@ namespace pa {
 static constexpr int NFFT = 1024;
 static constexpr int NC = 512;            // complex points
 static constexpr int FR_PER_WG = 32;
-static constexpr int MEL_WAVES = 8;
+static constexpr int MEL_WAVES = 4;
 static constexpr int XROW1 = 68;          // exchange-1 row stride (complex) : conflict-free reads
 static constexpr int XROW2 = 72;          // exchange-2 row stride (complex)
 static constexpr int WAVE_SCRATCH = 8 * XROW2 * 8;   // 4608 bytes
@@ -53,7 +63,7 @@ __device__ __forceinline__ cf tw1024(const float2* __restrict__ tw, int j) {
     return (j & 512) ? cf{-t.x, -t.y} : cf{t.x, t.y};
 }
 
-__global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restrict__ wave, int L,
+__global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const float* __restrict__ wave, int L,
                                                             const float* __restrict__ window,
                                                             const float* __restrict__ bin_mel,
                                                             const float2* __restrict__ twiddle,
@@ -62,10 +72,12 @@ __global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restri
     const int span = (FR_PER_WG - 1) * p.hop + NFFT;
     float* sSig = (float*)smem;                                        // [span] pre-emphasised, reflect-padded
     char* sScr = smem + ((span * 4 + 15) & ~15);                       // [8 waves][WAVE_SCRATCH]
-    float* sU = (float*)(sScr + MEL_WAVES * WAVE_SCRATCH);             // [512] up-slope weight of bin k
-    int* sJ = (int*)(sU + NC);                                         // [512] triangle index of bin k
-    int* sS = sJ + NC;                                                 // [n_mels + 3] first bin with j >= b
+    int* sS = (int*)(sScr + MEL_WAVES * WAVE_SCRATCH);                 // [n_mels + 3] first bin with j >= b
     float* sOut = (float*)(sS + 132);                                  // [n_mels][33]
+    // the two per-bin tables are only needed until every lane holds its 8 weights and sS is built: they live in the
+    // (not yet written) output tile, which keeps the workgroup under 80 KiB = two workgroups per CU
+    float* sU = sOut;                                                  // [512] up-slope weight of bin k
+    int* sJ = (int*)(sU + NC);                                         // [512] triangle index of bin k
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,15 +88,43 @@ __global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restri
     const float* x = wave + (int64_t)b * L;
 
     // ---- stage the signal span: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2 ----
-    for (int j = tid; j < span; j += 512) {
-        int i = f0 * p.hop + j - NFFT / 2;
-        if (i < 0) i = -i;
-        if (i >= Ly) i = 2 * (Ly - 1) - i;
-        i = max(0, min(i, Ly - 1));
-        sSig[j] = x[i + 1] - p.preemph * x[i];
+    constexpr int NT = MEL_WAVES * 64;
+    const int i0 = f0 * p.hop - NFFT / 2;                    // sample index of sSig[0]
+    if (i0 >= 0 && i0 + span + 4 <= Ly && ((i0 | L) & 3) == 0 && (span & 3) == 0 && span <= 12 * 4 * NT) {
+        // interior tile (no reflection, 16-byte aligned): one 16-byte load + the next sample per 4 outputs, every
+        // load of the tile issued before the first use (the loop has a compile-time trip count)
+        const float* xs = x + i0;
+        const int nv = span >> 2;
+        constexpr int MAXIT = 12;                             // 12 x 256 x 4 samples >= span for hop <= 362
+        f32x4 a[MAXIT];
+        float nx[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int t = tid + it * NT;
+            if (it * NT < nv) {                               // uniform; the lane predicate is folded into the address
+                const int tc = min(t, nv - 1);
+                a[it] = *(const f32x4*)(xs + 4 * tc);
+                nx[it] = xs[4 * tc + 4];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int t = tid + it * NT;
+            if (it * NT < nv && t < nv)
+                *(f32x4*)(sSig + 4 * t) = f32x4{a[it][1] - p.preemph * a[it][0], a[it][2] - p.preemph * a[it][1],
+                                                a[it][3] - p.preemph * a[it][2], nx[it] - p.preemph * a[it][3]};
+        }
+    } else {
+        for (int j = tid; j < span; j += NT) {
+            int i = i0 + j;
+            if (i < 0) i = -i;
+            if (i >= Ly) i = 2 * (Ly - 1) - i;
+            i = max(0, min(i, Ly - 1));
+            sSig[j] = x[i + 1] - p.preemph * x[i];
+        }
     }
     // ---- filterbank geometry for this call's (fmin, fmax): bin k -> triangle j_k, weight u_k ----
-    for (int k = tid; k < NC; k += 512) {
+    for (int k = tid; k < NC; k += NT) {
         const float t = (bin_mel[k] - p.mel_low) * p.inv_mel_delta;
         const float fl = floorf(t);
         sJ[k] = (int)fmaxf(fminf(fl, 100000.f), -1.f);
@@ -117,7 +157,12 @@ __global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restri
         }
     }
     cf* scr = (cf*)(sScr + wv * WAVE_SCRATCH);
-    float* pw = (float*)scr;                 // power spectrum overlays the scratch (513 floats)
+    float* up = (float*)scr;                 // per-bin contributions overlay the scratch (2 x 512 floats of its 1152)
+    float* dn = up + NC;
+    float bu[8];                             // up-slope weight of this lane's 8 bins k = lane + 64 s
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bu[q] = sU[lane + 64 * q];
+    __syncthreads();                         // sU / sJ are dead from here on: their LDS is the output tile
 
     for (int fi = 0; fi < FR_PER_WG / MEL_WAVES; ++fi) {
         const int fl = wv * (FR_PER_WG / MEL_WAVES) + fi;
@@ -169,27 +214,35 @@ __global__ __launch_bounds__(512) void mel_frontend_kernel(const float* __restri
             const cf X = cadd(e, xo);
             pk[s] = X.x * X.x + X.y * X.y;
         }
-        const cf z0 = scr[0];
+        // every bin feeds at most two triangles: store its two contributions, up[k] = P u (to triangle j_k) and
+        // dn[k] = P (1 - u) (to triangle j_k - 1), so that the band sums below read one value per bin
+        // (the Nyquist bin has no column in the kaldi bank: models/preprocess.py:73-74 pads a zero one)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) pw[lane + 64 * s] = pk[s];    // all reads of scr are issued above
-        if (lane == 0) { const float ny = z0.x - z0.y; pw[NC] = ny * ny; }
-        // sparse mel bands: this lane owns bands `lane` and `n_mels-1-lane` (one narrow + one wide)
+        for (int s = 0; s < 8; ++s) {                             // all reads of scr are issued above
+            up[lane + 64 * s] = pk[s] * bu[s];
+            dn[lane + 64 * s] = pk[s] - pk[s] * bu[s];
+        }
+        // sparse mel bands: this lane owns bands `lane` and `n_mels-1-lane` (one narrow + one wide): bins [k0, k1) on
+        // their up-slope, [k1, k2) on their down-slope; four independent partial sums keep four LDS reads in flight
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int band = h == 0 ? lane : p.n_mels - 1 - lane;
             // h == 0 covers bands 0..63; h == 1 covers the remaining 64..n_mels-1 in reverse
             const bool mine = h == 0 ? band < p.n_mels : band >= 64;
             if (!mine) continue;
-            float acc = 0.f;
             const int k0 = sS[band], k1 = sS[band + 1], k2 = sS[band + 2];
-            for (int k = k0; k < k1; ++k) acc += pw[k] * sU[k];
-            for (int k = k1; k < k2; ++k) acc += pw[k] * (1.0f - sU[k]);
-            sOut[band * (FR_PER_WG + 1) + fl] = acc;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = k0;
+            for (; k + 3 < k1; k += 4) { a0 += up[k]; a1 += up[k + 1]; a2 += up[k + 2]; a3 += up[k + 3]; }
+            for (; k < k1; ++k) a0 += up[k];
+            for (; k + 3 < k2; k += 4) { a0 += dn[k]; a1 += dn[k + 1]; a2 += dn[k + 2]; a3 += dn[k + 3]; }
+            for (; k < k2; ++k) a1 += dn[k];
+            sOut[band * (FR_PER_WG + 1) + fl] = (a0 + a1) + (a2 + a3);
         }
     }
     __syncthreads();
     // ---- epilogue: log, SpecAugment masks, affine; rows of 32 frames = 128 contiguous bytes ----
-    for (int idx = tid; idx < p.n_mels * FR_PER_WG; idx += 512) {
+    for (int idx = tid; idx < p.n_mels * FR_PER_WG; idx += NT) {
         const int mel = idx / FR_PER_WG, fl = idx % FR_PER_WG;
         const int t = f0 + fl;
         if (t >= T) continue;
@@ -213,8 +266,8 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     if (L - 1 <= NFFT / 2) return PA_EUNSUPPORTED;          // reflect padding needs L-1 > n_fft/2 (torch.stft rule)
     if (p->n_frames != pa_mel_num_frames(L, p->hop)) return PA_EINVAL;
     const int span = (FR_PER_WG - 1) * p->hop + NFFT;
-    const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH + NC * 4 + NC * 4 + 132 * 4 +
-                       (size_t)p->n_mels * (FR_PER_WG + 1) * 4;
+    const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH + 132 * 4 +
+                       std::max<size_t>((size_t)p->n_mels * (FR_PER_WG + 1) * 4, 2 * NC * 4);
     if (lds > 160 * 1024) return PA_EUNSUPPORTED;
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)mel_frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -222,7 +275,7 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     }();
     (void)attr_set;
     dim3 grid((unsigned)cdiv(p->n_frames, FR_PER_WG), (unsigned)B);
-    hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(512), lds, (hipStream_t)stream, wave, L, window, bin_mel,
+    hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(MEL_WAVES * 64), lds, (hipStream_t)stream, wave, L, window, bin_mel,
                        (const float2*)twiddle, out, *p);
     return check_launch();
 }

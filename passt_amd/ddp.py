@@ -39,20 +39,79 @@ def bucket_layout(named_sizes, depth):
     return spans
 
 
+class RcclAbiTransport:
+    """All-reduce through the library's own C-ABI entry points (pa_comm_init / pa_allreduce_bucket: RCCL resolved by the
+    library, no torch.distributed in the data path).  The 128-byte communicator id is handed out through whatever
+    torch.distributed group already exists (any backend; only ``broadcast_object_list`` is used, once).  Collectives
+    run on a dedicated HIP stream, ordered after the producer kernels by an event and joined by ``wait()``."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        lib = _lib.load()
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        box = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(lib.pa_comm_unique_id(buf), "pa_comm_unique_id")
+            box[0] = buf.raw
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=process_group)
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            comm = C.c_void_p()
+            _lib.check(lib.pa_comm_init(box[0], self.rank, self.world, C.byref(comm)), "pa_comm_init")
+        self.comm = comm
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def all_reduce(self, t):
+        """In-place sum of the contiguous f32 / bf16 tensor ``t`` over the ranks; returns a handle with wait()."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        t.record_stream(self.stream)
+        dt = self._lib.PA_F32 if t.dtype == torch.float32 else self._lib.PA_BF16
+        self._lib.check(self._lib.load().pa_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), dt, self.stream.cuda_stream),
+                        "pa_allreduce_bucket")
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        dev = self.device
+
+        class _Handle:
+            def wait(self_inner):
+                torch.cuda.current_stream(dev).wait_event(ev)
+        return _Handle()
+
+    def close(self):
+        if self.comm is not None:
+            self.stream.synchronize()
+            self._lib.check(self._lib.load().pa_comm_destroy(self.comm), "pa_comm_destroy")
+            self.comm = None
+
+
 class GradReducer:
     """comm_dtype "fp32": all-reduce the f32 gradient bucket in place (exact sum).  "bf16": gradient compression for
     the wire -- the bucket is cast to bf16, all-reduced (RCCL sums in bf16) and added back as f32: half the bytes per
     link (172 MB instead of 345 MB per step for passt_s), at bf16 rounding of the exchanged sums (not the reference's
     behaviour: opt-in)."""
 
-    def __init__(self, flat_grads, named_sizes, depth, process_group=None, comm_dtype="fp32"):
-        assert comm_dtype in ("fp32", "bf16")
+    def __init__(self, flat_grads, named_sizes, depth, process_group=None, comm_dtype="fp32", transport="torch"):
+        """transport "torch": torch.distributed collectives (backend nccl == RCCL on ROCm, gloo on CPU / in the tests);
+        "rccl_abi": the library's C-ABI collective entry (RcclAbiTransport)."""
+        assert comm_dtype in ("fp32", "bf16") and transport in ("torch", "rccl_abi")
         self.flat = flat_grads
         self.spans = bucket_layout(named_sizes, depth)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype
+        self.abi = RcclAbiTransport(flat_grads.device, process_group) if (transport == "rccl_abi" and self.world > 1) else None
         self.pending = []
+
+    def _all_reduce(self, t):
+        if self.abi is not None:
+            return self.abi.all_reduce(t)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def broadcast_(self, flat_params, src=0):
         """Make every rank's parameters equal to rank ``src``'s (in place)."""
@@ -68,11 +127,10 @@ class GradReducer:
         # torch.distributed orders the collective after everything already enqueued on the current stream (the
         # kernels that produced this bucket) and runs it on the backend's communication stream
         if self.comm_dtype == "fp32":
-            self.pending.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True),
-                                 None, s, e))
+            self.pending.append((self._all_reduce(self.flat[s:e]), None, s, e))
         else:
             wire = self.flat[s:e].to(torch.bfloat16)
-            self.pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), wire, s, e))
+            self.pending.append((self._all_reduce(wire), wire, s, e))
 
     def wait(self):
         for w, wire, s, e in self.pending:

@@ -17,7 +17,7 @@ from .passt import passt_backward, passt_forward
 
 class TrainStep:
     def __init__(self, net, mel=None, lr=2e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, optimizer="adamw",
-                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce", comm_dtype="fp32"):
+                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce", comm_dtype="fp32", transport="torch"):
         self.net, self.mel = net, mel
         self.lr, self.wd, self.betas, self.eps, self.optimizer = lr, weight_decay, betas, eps, optimizer
         self.mixup_alpha, self.use_mixup = mixup_alpha, use_mixup
@@ -46,7 +46,7 @@ class TrainStep:
         self.m = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
         self.v = torch.zeros_like(self.flat_p) if optimizer == "adamw" else None
         self.reducer = GradReducer(self.flat_g, [(n, p.numel()) for n, p in self.named], len(net.blocks), process_group,
-                                   comm_dtype=comm_dtype)
+                                   comm_dtype=comm_dtype, transport=transport)
         # identical replicas: rank 0's parameters everywhere (what Lightning's DDP wrapper does at construction,
         # ex_audioset.py:488-489); a caller that seeded per rank or loaded different state must not train diverging copies
         self.reducer.broadcast_(self.flat_p)

@@ -167,3 +167,18 @@ def test_reference_module_paths_resolve_to_this_implementation():
     assert mp.get_model is passt_amd.passt.get_model and mp.PaSST is passt_amd.PaSST
     assert mpre.AugmentMelSTFT is passt_amd.AugmentMelSTFT
     assert mp.get_model_passt is mp.get_model
+
+
+def test_comm_entry_points_without_a_gpu():
+    """pa_comm_*: argument checks and the out-of-band id need no device (RCCL itself is loaded lazily by the library)."""
+    import ctypes as C
+    from passt_amd import _lib
+    lib = _lib.load()
+    assert lib.pa_comm_init(None, 0, 1, None) == -1 and lib.pa_allreduce_bucket(None, None, 0, 0, None) == -1
+    assert lib.pa_comm_destroy(None) == -1 and lib.pa_comm_unique_id(None) == -1
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    rc = lib.pa_comm_unique_id(buf)
+    if rc == 0:
+        assert any(buf.raw)                                   # an ncclUniqueId was produced
+    else:                                                     # a box without librccl: a clean error, not a crash
+        assert rc == -4 and b"rccl" in lib.pa_comm_last_error().lower()

@@ -75,3 +75,21 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(tmp_path, variant
     else:
         e = float((d_dp - d_ref).abs().max() / d_ref.abs().max())
         assert e < (1e-4 if variant != "bf16_wire" else 1e-2), e
+
+
+def test_rccl_abi_transport_single_rank():
+    """The C-ABI collective entry (pa_comm_init / pa_allreduce_bucket, RCCL loaded by the library) on the one GPU a test
+    box has: a world of 1 is the identity, for both wire types, ordered on the transport's own stream; a second bucket
+    reuses the communicator.  (Two ranks need two devices: the 8-GPU scaling run is the driver's.)"""
+    from passt_amd.ddp import RcclAbiTransport
+    tr = RcclAbiTransport("cuda:0")
+    assert tr.world == 1 and tr.rank == 0
+    a = torch.randn(1 << 20, device="cuda")
+    b = (torch.randn(4099, device="cuda")).to(torch.bfloat16)
+    a0, b0 = a.clone(), b.clone()
+    h1, h2 = tr.all_reduce(a), tr.all_reduce(b)
+    h1.wait()
+    h2.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    tr.close()
