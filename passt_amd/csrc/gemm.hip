@@ -853,13 +853,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + min(n0 + wc * 64 + lane, a.N - 1)),
                                                  (__attribute__((address_space(3))) void*)(smem + G::BIAS_OFF + wc * 256), 4, 0, 0);
         }
+        // the accumulators are NOT cleared: the first k-substep of an item issues its MFMAs with C = 0 (mma32_first), which
+        // saves TM x 32 v_mov per wave and item in the seam between two items
         f32x16 acc[TM][2];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
         if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
         PA_PROBE_STAMP(round < 24, round * 16);
@@ -896,12 +892,28 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 __builtin_amdgcn_s_barrier();
                 // ---------------- M segment ----------------
                 __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int u = 0; u < SUB; ++u)
+                // (r02, measured and rejected: hitting the closing barrier 1..3 MFMAs EARLY, so that the barrier's ~100-cycle
+                // resolution overlaps the tail of the M segment, is 3..7 % SLOWER -- the tail MFMAs then share the SIMD's matrix
+                // pipe with the other group's first ones: profiles/r02_kloop_experiments.json)
+                if (ph == 0 && t == 0) {              // uniform: first substep of the item starts the accumulation chains
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
+                        for (int j = 0; j < 2; ++j) mma32_first<T>(acc[i][j], fa[0][i], fb[0][j]);
+#pragma unroll
+                    for (int u = 1; u < SUB; ++u)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SUB; ++u)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if (ph == NPH - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -1280,13 +1292,15 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         }
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][2];                 // started by the first token step's MFMAs (C = 0), cleared only for an empty slice
+    if (nsteps <= 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1346,10 +1360,17 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
             __builtin_amdgcn_s_barrier();
             // ---------------- M segment ----------------
             __builtin_amdgcn_s_setprio(1);
+            if (ph == 0 && t == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
+                    for (int j = 0; j < 2; ++j) mma32_first<bf16>(acc[i][j], fa[i], fb[j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
+            }
             __builtin_amdgcn_s_setprio(0);
             if (ph == 3 && wr == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

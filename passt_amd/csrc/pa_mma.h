@@ -28,6 +28,22 @@ __device__ __forceinline__ void mma32<float>(f32x16& acc, const f32x4& a, const 
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
 }
 
+// first product of an accumulation chain: acc = a * b (C operand = the inline constant 0: no zero-filled registers)
+template <typename T>
+__device__ __forceinline__ void mma32_first(f32x16& acc, const typename Frag<T>::type& a, const typename Frag<T>::type& b);
+template <>
+__device__ __forceinline__ void mma32_first<bf16>(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma32_first<float>(f32x16& acc, const f32x4& a, const f32x4& b) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], z, 0, 0, 0);
+#pragma unroll
+    for (int e = 1; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+}
+
 // row of accumulator register r for this lane
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -272,7 +272,20 @@ def pick_split_k_slots(tiles, steps, slots=256):
     return best
 
 
+_SPLITS_CACHE = {}
+
+
 def pick_batched_splits(probs, slots=256):
+    """Memoised front of _pick_batched_splits (the search walks ~470 slice lengths in Python: ~1 ms per call, and the step
+    asks the same question once per transformer block)."""
+    key = (tuple(probs), slots)
+    hit = _SPLITS_CACHE.get(key)
+    if hit is None:
+        hit = _SPLITS_CACHE[key] = _pick_batched_splits(list(probs), slots)
+    return hit
+
+
+def _pick_batched_splits(probs, slots=256):
     """probs: [(tiles, k_steps)] of the problems sharing one launch.  Every work item is one 256x256 tile x one K slice of
     L steps (S_p = ceil(steps_p / L)).  Cost model (us, MI355X measurements): rounds x (L + 3) x 1.6 for the K loops and
     per-item epilogues, with rounds = ceil(#items / slots), plus 0.05 per item for the f32 partial slab it writes and the
