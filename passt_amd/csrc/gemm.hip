@@ -310,8 +310,11 @@ __device__ __forceinline__ void gemm_epilogue_f32_direct(const pa_gemm_args& a, 
 #ifndef PA_EPILOGUE_V2
 #define PA_EPILOGUE_V2 1
 #endif
-#ifndef PA_V2_DEPTH
-#define PA_V2_DEPTH 2          // 32-row passes of auxiliary rows (residual / pre-activation) requested ahead of their use
+#ifndef PA_V2_DEPTH_X
+#define PA_V2_DEPTH_X 2        // DGELU: 32-row passes of pre-activation rows requested ahead of their use (16 registers each)
+#endif
+#ifndef PA_V2_DEPTH_R
+#define PA_V2_DEPTH_R 1        // RESID: 32-row passes of residual rows requested ahead (32 registers each; 2 spills at TM = 4)
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_bits_t;
@@ -326,9 +329,59 @@ __device__ __forceinline__ auto tile_rsrc(const void* origin, int64_t bytes) {
 }
 static constexpr uint32_t V2_OOB = 0x80000000u;     // a lane offset no descriptor of < 2 GiB contains
 
+// Auxiliary rows of an item's epilogue (DGELU: pre-activation, RESID: residual): descriptor + the row vectors requested
+// ahead of their use.  The kernel calls issue() DURING the last K-tile of the item (the first rows come from HBM, not from
+// a cache: requested at the start of the epilogue their ~2-3k-cycle latency was exposed once per item), the epilogue
+// consumes the slots and refills them.  issue() is unconditional and always emits V2Aux::N loads: the K loop's counted
+// vmcnt wait relies on that number (rows / columns outside the matrix fall outside the descriptor and read as 0).
+template <int EPI, int TM> struct V2Aux {
+    static constexpr bool X = EPI == PA_EPI_DGELU, R = EPI == PA_EPI_RESID;
+    static constexpr int PASSES = X ? (PA_V2_DEPTH_X < TM ? PA_V2_DEPTH_X : TM) : 0;                    // DGELU: 32-row passes in flight
+    static constexpr int HALVES = R ? (PA_V2_DEPTH_R < TM ? 2 * PA_V2_DEPTH_R : 2 * TM) : 0;        // RESID: 16-row half passes
+    static constexpr int N = X ? PASSES * 4 : HALVES * 4;                                           // loads per wave in issue()
+    u32x4 v[N > 0 ? N : 1];
+    decltype(tile_rsrc(nullptr, 0)) rs;
+    uint32_t vofs, ld;
+
+    __device__ __forceinline__ void issue(const pa_gemm_args& a, int m0, int n0, int wr, int wc, int lane) {
+        if constexpr (N > 0) {
+            const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
+            const bool exists = mb < a.M && nb < a.N;
+            if constexpr (X) {
+                ld = (uint32_t)a.ldaux * 2u;
+                rs = tile_rsrc((const char*)a.aux + ((int64_t)mb * a.ldaux + nb) * 2, exists ? ((int64_t)(a.M - mb - 1) * a.ldaux + (a.N - nb)) * 2 : 0);
+                const int g = lane & 7;
+                vofs = nb + g * 8 < a.N ? (uint32_t)(2 * (lane >> 3)) * ld + (uint32_t)g * 16u : V2_OOB;
+#pragma unroll
+                for (int i = 0; i < PASSES; ++i) load_pass(i, i);
+            } else {
+                ld = (uint32_t)a.ldr * 4u;
+                rs = tile_rsrc((const char*)a.resid + ((int64_t)mb * a.ldr + nb) * 4, exists ? ((int64_t)(a.M - mb - 1) * a.ldr + (a.N - nb)) * 4 : 0);
+                const int er = lane >> 4, sl = lane & 15;
+                vofs = nb + sl * 4 < a.N ? (uint32_t)er * ld + (uint32_t)sl * 16u : V2_OOB;
+#pragma unroll
+                for (int hp = 0; hp < HALVES; ++hp) load_half(hp, hp);
+            }
+        }
+    }
+    // DGELU: rows 2p, 2p+1 of task t (p = lane>>3 + 8t) of pass i  ->  v[slot*4 + t*2 + q]
+    __device__ __forceinline__ void load_pass(int slot, int i) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                v[slot * 4 + t * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(i * 32 + 16 * t + q) * ld, 0, 0);
+    }
+    // RESID: rows it*4 + (lane>>4) of half pass hp  ->  v[slot*4 + it]
+    __device__ __forceinline__ void load_half(int slot, int hp) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) v[slot * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(hp * 16 + it * 4) * ld, 0, 0);
+    }
+};
+
 template <int EPI, int TM>
 __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* slab, const float* bias_row,
-                                                      int m0, int n0, int wr, int wc, int lane, int colsum_row) {
+                                                      int m0, int n0, int wr, int wc, int lane, int colsum_row, V2Aux<EPI, TM>& aux) {
     static_assert(EPI == PA_EPI_STORE || EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU, "bf16 outputs");
     const int h = lane >> 5, c = lane & 31;
     const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;          // uniform: origin of this wave's tile
@@ -363,63 +416,41 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
         ors2 = tile_rsrc((const char*)a.out_lp2 + ((int64_t)mb * a.ldolp2 + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp2 + (a.N - nb)) * 2);
         vo2 = colok ? (uint32_t)(2 * (lane >> 3)) * ld2b + (uint32_t)g * 16u : V2_OOB;
     }
-    uint32_t ldx2 = 0, vx = 0;
-    auto xrs = ors;
-    constexpr int XD = EPI == PA_EPI_DGELU ? (PA_V2_DEPTH < TM ? PA_V2_DEPTH : TM) : 1;
-    constexpr int XOFF = 4096;         // DGELU: the pre-activation goes through the second half of the wave's slab
-    u32x4 xr[XD][2][2];
-    auto load_x = [&](int slot, int i) {        // pre-activation row vectors of pass i (rows 2p, 2p+1 of task t)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                xr[slot][t][q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx + (uint32_t)(i * 32 + 16 * t + q) * ldx2, 0, 0);
-    };
-    if constexpr (EPI == PA_EPI_DGELU) {
-        ldx2 = (uint32_t)a.ldaux * 2u;
-        xrs = tile_rsrc((const char*)a.aux + ((int64_t)mb * a.ldaux + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldaux + (a.N - nb)) * 2);
-        vx = colok ? (uint32_t)(2 * (lane >> 3)) * ldx2 + (uint32_t)g * 16u : V2_OOB;
-#pragma unroll
-        for (int i = 0; i < XD; ++i) load_x(i, i);
-    }
+    constexpr int XD = V2Aux<EPI, TM>::PASSES > 0 ? V2Aux<EPI, TM>::PASSES : 1;
     float csum[2] = {0.f, 0.f};
-    // The passes are software pipelined by hand: the LDS round trip (and, for DGELU, the pre-activation's way into the
-    // accumulator layout) of one pass runs under the polynomial math of the next one -- the epilogue is VALU bound (GELU:
-    // ~14 VALU per output, 128 outputs per lane, two waves per SIMD) and the two waves of a SIMD run in step, so
-    // whatever is not overlapped inside a wave is not overlapped at all.
-    auto x_to_slab = [&](int i) {      // DGELU: pre-activation rows of pass i -> pair dwords -> slab (two 16-byte writes per task)
+    // (r02: running the LDS round trip of pass i under the polynomial math of pass i+1 -- software pipelining by hand --
+    // measured no faster, 15.3k vs 14.0k cycles per 256x256 GELU tile, and costs ~50 registers: the passes stay sequential)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const u32x4 x0 = xr[i % XD][t][0], x1 = xr[i % XD][t][1];      // rows 2p, 2p+1; dword q = columns 8g+2q, 8g+2q+1
-            const u32x4 e0 = {perm_lo16(x1[0], x0[0]), perm_hi16(x1[0], x0[0]), perm_lo16(x1[1], x0[1]), perm_hi16(x1[1], x0[1])};
-            const u32x4 e1 = {perm_lo16(x1[2], x0[2]), perm_hi16(x1[2], x0[2]), perm_lo16(x1[3], x0[3]), perm_hi16(x1[3], x0[3])};
-            *(u32x4*)(r0 + XOFF + t * 2048) = e0;
-            *(u32x4*)(r1 + XOFF + t * 2048) = e1;
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);       // keep the passes apart: hoisting every pass's math to the top spills
+        if constexpr (EPI == PA_EPI_DGELU) {
+            // pre-activation rows -> pair dwords -> slab (two 16-byte writes per task) -> accumulator layout
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 x0 = aux.v[(i % XD) * 4 + t * 2], x1 = aux.v[(i % XD) * 4 + t * 2 + 1];   // rows 2p, 2p+1; dword q = columns 8g+2q, 8g+2q+1
+                const u32x4 e0 = {perm_lo16(x1[0], x0[0]), perm_hi16(x1[0], x0[0]), perm_lo16(x1[1], x0[1]), perm_hi16(x1[1], x0[1])};
+                const u32x4 e1 = {perm_lo16(x1[2], x0[2]), perm_hi16(x1[2], x0[2]), perm_lo16(x1[3], x0[3]), perm_hi16(x1[3], x0[3])};
+                *(u32x4*)(r0 + t * 2048) = e0;
+                *(u32x4*)(r1 + t * 2048) = e1;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the refill below must not be hoisted above the reads of its slot
+            if (i + XD < TM) aux.load_pass(i % XD, i + XD);
         }
-    };
-    uint32_t xw[2][8];                 // DGELU: pre-activation pairs of the pass about to be computed, accumulator layout
-    auto x_from_slab = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xw[j][k] = *(const uint32_t*)(wbase + XOFF + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
-    };
-    uint32_t pk[2][8], pk2[2][8];
-    auto math = [&](int i) {           // accumulators of pass i -> packed bf16 pairs (and the activation / the product with GELU')
         const int rows_left = a.M - mb - i * 32;       // rows of this pass that exist (uniform): only the column sums need it
+        uint32_t pk[2][8], pk2[2][8];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 f32x2 v = {acc[i][j][2 * k] + b2[j], acc[i][j][2 * k + 1] + b2[j]};
                 if constexpr (EPI == PA_EPI_DGELU) {
-                    const f32x2 x = {__builtin_bit_cast(float, xw[j][k] << 16), __builtin_bit_cast(float, xw[j][k] & 0xffff0000u)};
+                    const uint32_t xw = *(const uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
+                    const f32x2 x = {__builtin_bit_cast(float, xw << 16), __builtin_bit_cast(float, xw & 0xffff0000u)};
                     v = v * (PA_PROBE_FLAG(a, 2) ? x : gelu_grad_fast2(x));
-                    if (rows_left >= 32) {
-                        csum[j] += v[0] + v[1];
-                    } else {         // last row tile of the matrix: rows >= M hold duplicates of row M-1
+                    csum[j] += v[0] + v[1];
+                    if (rows_left < 32) {        // last row tile of the matrix (uniform branch): rows >= M hold duplicates of row M-1
                         const int row = 2 * ((k & 1) + 4 * (k >> 1) + 2 * h);
-                        csum[j] += (row < rows_left ? v[0] : 0.f) + (row + 1 < rows_left ? v[1] : 0.f);
+                        csum[j] -= (row < rows_left ? 0.f : v[0]) + (row + 1 < rows_left ? 0.f : v[1]);
                     }
                 }
                 pk[j][k] = cvt_pk_bf16(v[0], v[1]);
@@ -428,17 +459,6 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                     pk2[j][k] = cvt_pk_bf16(gl[0], gl[1]);
                 }
             }
-    };
-    if constexpr (EPI == PA_EPI_DGELU) {
-        x_to_slab(0);
-        if (XD < TM) load_x(0, XD);
-        x_from_slab();
-    }
-    math(0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        // pass i: packed pairs -> slab; its row reads are issued right away ...
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -447,30 +467,11 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                 if constexpr (EPI == PA_EPI_GELU) *(uint32_t*)(wbase + 4096 + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk2[j][k];
             }
         // same-wave LDS accesses execute in order: no barrier between the writes and the reads
-        u32x4 d[EPI == PA_EPI_GELU ? 2 : 1][2][2];
 #pragma unroll
         for (int o = 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                d[o][t][0] = *(const u32x4*)(r0 + o * 4096 + t * 2048);
-                d[o][t][1] = *(const u32x4*)(r1 + o * 4096 + t * 2048);
-            }
-        if constexpr (EPI == PA_EPI_DGELU) {
-            if (i + 1 < TM) {
-                x_to_slab(i + 1);
-                if (i + 1 + XD < TM) load_x((i + 1) % XD, i + 1 + XD);
-                x_from_slab();
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ... and land under the math of pass i+1
-        if (i + 1 < TM) math(i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int o = 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const u32x4 d0 = d[o][t][0], d1 = d[o][t][1];
+                const u32x4 d0 = *(const u32x4*)(r0 + o * 4096 + t * 2048), d1 = *(const u32x4*)(r1 + o * 4096 + t * 2048);
                 const u32x4 lo = {perm_lo16(d0[1], d0[0]), perm_lo16(d0[3], d0[2]), perm_lo16(d1[1], d1[0]), perm_lo16(d1[3], d1[2])};
                 const u32x4 hi = {perm_hi16(d0[1], d0[0]), perm_hi16(d0[3], d0[2]), perm_hi16(d1[1], d1[0]), perm_hi16(d1[3], d1[2])};
                 const uint32_t ldb = o ? ld2b : ld2;
@@ -495,7 +496,7 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
 // f32 residual epilogue through LDS: out[m][n] = acc + bias[n] + resid[m][n]
 template <int TM>
 __device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* slab, const float* bias_row,
-                                                       int m0, int n0, int wr, int wc, int lane) {
+                                                       int m0, int n0, int wr, int wc, int lane, V2Aux<PA_EPI_RESID, TM>& aux) {
     const int h = lane >> 5, c = lane & 31;
     const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
     if (mb >= a.M || nb >= a.N) return;
@@ -505,20 +506,11 @@ __device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f3
     float b2[2] = {0.f, 0.f};
     if (bias_row) { b2[0] = bias_row[wc * 64 + c]; b2[1] = bias_row[wc * 64 + 32 + c]; }
     const bool colok = nb + sl * 4 < a.N;                              // ld % 4 == 0 and N % 8 == 0: the lane's 4 columns are all in or out
-    const uint32_t ldr4 = (uint32_t)a.ldr * 4u, ldo4 = (uint32_t)a.ldo32 * 4u;
-    const auto rrs = tile_rsrc((const char*)a.resid + ((int64_t)mb * a.ldr + nb) * 4, ((int64_t)(a.M - mb - 1) * a.ldr + (a.N - nb)) * 4);
+    const uint32_t ldo4 = (uint32_t)a.ldo32 * 4u;
     const auto ors = tile_rsrc((const char*)a.out_f32 + ((int64_t)mb * a.ldo32 + nb) * 4, ((int64_t)(a.M - mb - 1) * a.ldo32 + (a.N - nb)) * 4);
-    const uint32_t vr = colok ? (uint32_t)er * ldr4 + (uint32_t)sl * 16u : V2_OOB, vo = colok ? (uint32_t)er * ldo4 + (uint32_t)sl * 16u : V2_OOB;
-    // residual rows: DEPTH half passes (16 rows = 4 vectors per lane) are requested ahead of their use
-    constexpr int NH = 2 * TM, DEPTH = 2 * PA_V2_DEPTH < NH ? 2 * PA_V2_DEPTH : NH;
-    f32x4 xr[DEPTH][4];
-    auto load_half = [&](int slot, int hp) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            xr[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, vr + (uint32_t)(hp * 16 + it * 4) * ldr4, 0, 0));
-    };
-#pragma unroll
-    for (int hp = 0; hp < DEPTH; ++hp) load_half(hp, hp);
+    const uint32_t vo = colok ? (uint32_t)er * ldo4 + (uint32_t)sl * 16u : V2_OOB;
+    // residual rows: DEPTH half passes (16 rows = 4 vectors per lane) were requested during the last K-tile (V2Aux)
+    constexpr int NH = 2 * TM, DEPTH = V2Aux<PA_EPI_RESID, TM>::HALVES;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __builtin_amdgcn_sched_barrier(0);       // keep the passes apart (register pressure)
@@ -532,9 +524,10 @@ __device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f3
             const int hp = 2 * i + hh;
             f32x4 o[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) o[it] = *(const f32x4*)(rdbase + (hh * 4 + it) * 1024) + xr[hp % DEPTH][it];
+            for (int it = 0; it < 4; ++it)
+                o[it] = *(const f32x4*)(rdbase + (hh * 4 + it) * 1024) + __builtin_bit_cast(f32x4, aux.v[(hp % DEPTH) * 4 + it]);
             __builtin_amdgcn_sched_barrier(0);   // the refill must not be hoisted above the adds (it would get fresh registers)
-            if (hp + DEPTH < NH) load_half(hp % DEPTH, hp + DEPTH);
+            if (hp + DEPTH < NH) aux.load_half(hp % DEPTH, hp + DEPTH);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[it]), ors, vo + (uint32_t)(hp * 16 + it * 4) * ldo4, 0, 0);
@@ -856,6 +849,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         // the accumulators are NOT cleared: the first k-substep of an item issues its MFMAs with C = 0 (mma32_first), which
         // saves TM x 32 v_mov per wave and item in the seam between two items
         f32x16 acc[TM][2];
+        constexpr bool USE_V2 = PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL;
+        constexpr int AUX_EPI = USE_V2 ? EPI : PA_EPI_STORE;
+        V2Aux<AUX_EPI, TM> aux;
+        constexpr int AUXN = V2Aux<AUX_EPI, TM>::N;
         const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
         if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
         PA_PROBE_STAMP(round < 24, round * 16);
@@ -886,7 +883,15 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                     if (ph == 0) dmaA(gbuf ^ 1, dstep);
                     if (ph == (NPH == 4 ? 1 : 0)) dmaB(gbuf ^ 1, dstep);
                 }
-                if (ph == NPH - 1 && wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // last K-tile of the item: request the first auxiliary rows of its epilogue now, AFTER this tile's LDS-DMA
+                // (vmcnt retires in issue order -- tests/probes/probe_store.hip -- so the end-of-tile wait below can leave
+                // exactly these AUXN youngest loads in flight: they land under the remaining MFMAs)
+                if constexpr (USE_V2 && AUXN > 0) {
+                    if (last && ph == NPH / 2) aux.issue(a, cur_m0, cur_n0, wr, wc, lane);
+                }
+                if (ph == NPH - 1 && wr == 1) {
+                    if (USE_V2 && AUXN > 0 && last) wait_vmcnt<AUXN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -915,7 +920,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                             for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (ph == NPH - 1 && wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (ph == NPH - 1 && wr == 0) {
+                    if (USE_V2 && AUXN > 0 && last) wait_vmcnt<AUXN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
@@ -937,8 +944,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             // straight-line epilogue; matrix edges are handled by the buffer descriptors (launch_gemm_stagger keeps the
             // row-remapped patch-embedding form and matrices >= 2 GiB away from this kernel)
             const float* brow = HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr;
-            if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane);
-            else gemm_epilogue_v2_bf16<EPI, TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr);
+            if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, aux);
+            else gemm_epilogue_v2_bf16<EPI, TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr, aux);
         } else if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
             (void)slab;
             gemm_epilogue_f32_direct<EPI, TM>(a, acc, HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr, cur_m0,
