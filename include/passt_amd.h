@@ -180,6 +180,12 @@ int pa_gemm_tn(const pa_gemm_args* a, void* stream);
  * between problems and items of different length pack onto the CUs.  Same arguments and results as n calls of
  * pa_gemm_tn; `a` is a HOST array. */
 #define PA_TN_BATCH_MAX 4
+/* tokens the bf16 role-split weight-gradient kernel consumes per pipeline stage: a K slice of pa_gemm_tn /
+ * pa_gemm_tn_batched is ceil(ceil(K / PA_TN_STEP_ROWS) / split_k) such steps (callers sizing split_k use it) */
+#ifndef PA_TN_STEP_ROWS
+#define PA_TN_STEP_ROWS 48
+#endif
+int pa_gemm_tn_step_rows(void);    /* the value the library was built with */
 int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream);
 /* Row gather / scatter and strided zero fill (prefix-token path of the last block):
  * gather: out[i] = in[idx[i]]; scatter: out[idx[i]] = in[i]; rows of row_bytes bytes (multiple of 4). */

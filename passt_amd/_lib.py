@@ -58,6 +58,7 @@ SIGNATURES = {
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn_batched": (i32, [C.POINTER(GemmArgs), i32, vp]),
+    "pa_gemm_tn_step_rows": (i32, []),
     "pa_reduce_partials_batched": (i32, [C.POINTER(ReduceDesc), i32, vp]),
     "pa_colsum_ws_floats": (i64, [i32, i32]),
     "pa_colsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp]),

@@ -730,24 +730,42 @@ static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
 // of the current one, so the K loop runs without a prologue bubble across items, and the epilogue's slabs
 // live in the K-tile buffer that was read last (+ a few KiB past the ring), never in the one already
 // holding the next item's data.
-template <int TM> struct StaggerGeom {
+// A3 (r02): the A operand (activations) gets THREE ring slots and is requested TWO K-tiles ahead, the B operand (weights,
+// L2 resident) keeps two slots / one tile.  In the training step the activation panels come from HBM (the 140-186 MB
+// operands of the K = 2304 / 3072 input-gradient GEMMs do not survive in the 256 MB Infinity Cache between producer and
+// consumer), and one K-tile of lead (~1.1-1.4 us) is less than a loaded HBM round trip: those GEMMs ran 21-23 % slower in
+// the step than alone on cache-resident data (profiles/r02_instep_vs_isolated.json).  Needs TM <= 3 (LDS) and >= 2 K-tiles.
+template <int TM, bool A3> struct StaggerGeom {
     static constexpr int TBM = 64 * TM, TBN = 256;
     static constexpr int A_BYTES = TBM * KB, B_BYTES = TBN * KB, STAGE_BYTES = A_BYTES + B_BYTES;   // 48/56/64 KiB
+    static constexpr int NA = A3 ? 3 : 2;
+    static constexpr int RING = NA * A_BYTES + 2 * B_BYTES;
+    // ring layout.  !A3: [A0 B0][A1 B1] (a K-tile's operands adjacent: the epilogue slabs take one whole stage);
+    //               A3 : [A0 A1 A2][B0 B1]
+    __host__ __device__ static constexpr int a_off(int s) { return A3 ? s * A_BYTES : s * STAGE_BYTES; }
+    __host__ __device__ static constexpr int b_off(int s) { return A3 ? 3 * A_BYTES + s * B_BYTES : s * STAGE_BYTES + A_BYTES; }
+    // epilogue slabs live in the ring slots consumed last.  !A3: SLAB_BYTES each, SLABS_IN_STAGE of them in that stage;
+    // A3: 8 KiB each (what epilogue v2 needs), SLABS_A in the free A slot, 4 in the free B slot; the rest past the ring
+    static constexpr int SLAB = A3 ? 8192 : SLAB_BYTES;
     static constexpr int SLABS_IN_STAGE = STAGE_BYTES / SLAB_BYTES;                                 // 5 / 6 / 7
-    static constexpr int BIAS_OFF = 2 * STAGE_BYTES + (8 - SLABS_IN_STAGE) * SLAB_BYTES;    // 256 floats: the tile's bias row
+    static constexpr int SLABS_A = A_BYTES / 8192, SLABS_B = B_BYTES / 8192;
+    static constexpr int EXTRA = A3 ? 8 - SLABS_A - SLABS_B : 8 - SLABS_IN_STAGE;
+    static constexpr int BIAS_OFF = RING + EXTRA * SLAB;    // 256 floats: the tile's bias row
     static constexpr int TAB_OFF = BIAS_OFF + 1024;         // {m0, n0, split, -} of this workgroup's item in every round
-    static constexpr int MAX_ROUNDS = 512;
+    static constexpr int MAX_ROUNDS = A3 ? 128 : 512;
     static constexpr int LDS = TAB_OFF + MAX_ROUNDS * 16;
 };
 
-template <typename T, int EPI, int TM>
+template <typename T, int EPI, int TM, bool A3 = false>
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                               const int nwg, const int ksteps_per_split, const int total) {
-    using G = StaggerGeom<TM>;
+    using G = StaggerGeom<TM, A3>;
     constexpr int WN = 4;
     constexpr int TBM = G::TBM, TBN = G::TBN;         // TM = 2/3/4 -> 128/192/256-row tiles (tile quantisation)
     constexpr int A_PER = TM;                         // A copies per wave per stage: TBM*128/1024/8
-    constexpr int A_BYTES = G::A_BYTES, STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int NA = G::NA, PDA = NA - 1;           // A ring slots; K-tiles of lead of the A requests (B: always 1)
+    constexpr bool USE_V2 = PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL;
+    static_assert(!A3 || (TM <= 3 && (USE_V2 || EPI == PA_EPI_PARTIAL)), "A3: LDS budget / 8 KiB slabs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -775,20 +793,24 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     for (int i = tid; i < 2 * PROBE_SLOTS; i += 512) ((unsigned long long*)(smem + G::LDS))[i] = 0ull;
 #endif
     __syncthreads();
-    // DMA cursor of the item whose K-tiles are being fetched: a uniform 64-bit base per operand (SGPRs: tile
-    // origin + K offset) plus per-lane 32-bit offsets (row within the tile, clamped at the matrix edge, and the
-    // swizzled 16-byte chunk) -- a handful of VALU per tile and none per K-tile.
+    // DMA cursors, one per operand (A runs PDA tiles ahead of the MFMAs, B one: near an item's end they point at
+    // different items): a uniform 64-bit base (SGPRs: tile origin + K offset) plus per-lane 32-bit offsets (row within
+    // the tile, clamped at the matrix edge, and the swizzled 16-byte chunk) -- a handful of VALU per item, none per K-tile.
     const char* baseA;
     const char* baseB;
     uint32_t voffA[A_PER], voffB[4];
-    auto point_at = [&](int r, int& m0, int& n0, int& split) {
+    auto item_of = [&](int r, int& m0, int& n0, int& split) {
         const int4 e = tab[r];
         m0 = __builtin_amdgcn_readfirstlane(e.x);
         n0 = __builtin_amdgcn_readfirstlane(e.y);
         split = __builtin_amdgcn_readfirstlane(e.z);
         const int ks_begin = split * ksteps_per_split;
-        baseA = (const char*)a.A + (int64_t)m0 * a.lda * sizeof(T) + (int64_t)ks_begin * KB;
-        baseB = (const char*)a.B + (int64_t)n0 * a.ldb * sizeof(T) + (int64_t)ks_begin * KB;
+        return min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;     // K-tiles of the item (>= 1, see launch)
+    };
+    auto point_A = [&](int r) {
+        int m0, n0, split;
+        item_of(r, m0, n0, split);
+        baseA = (const char*)a.A + (int64_t)m0 * a.lda * sizeof(T) + (int64_t)split * ksteps_per_split * KB;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int q = (wave * A_PER + i) * 64 + lane;
@@ -796,6 +818,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             const int c = (q & 7) ^ swz_f128(row);
             voffA[i] = (uint32_t)min(row, a.M - 1 - m0) * (uint32_t)(a.lda * (int)sizeof(T)) + c * 16;
         }
+    };
+    auto point_B = [&](int r) {
+        int m0, n0, split;
+        item_of(r, m0, n0, split);
+        baseB = (const char*)a.B + (int64_t)n0 * a.ldb * sizeof(T) + (int64_t)split * ksteps_per_split * KB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = (wave * 4 + i) * 64 + lane;
@@ -803,18 +830,17 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             const int c = (q & 7) ^ swz_f128(row);
             voffB[i] = (uint32_t)min(row, a.N - 1 - n0) * (uint32_t)(a.ldb * (int)sizeof(T)) + c * 16;
         }
-        return min(ksteps_total, ks_begin + ksteps_per_split) - ks_begin;     // K-tiles of the item (>= 1, see launch)
     };
-    auto dmaA = [&](int buf, int step) {
-        char* sA = smem + buf * STAGE_BYTES + wave * (A_PER * 1024);
+    auto dmaA = [&](int slot, int step) {
+        char* sA = smem + G::a_off(slot) + wave * (A_PER * 1024);
         const char* sb = baseA + (int64_t)step * KB;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffA[i]),
                                              (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
     };
-    auto dmaB = [&](int buf, int step) {
-        char* sB = smem + buf * STAGE_BYTES + A_BYTES + wave * 4096;
+    auto dmaB = [&](int slot, int step) {
+        char* sB = smem + G::b_off(slot) + wave * 4096;
         const char* sb = baseB + (int64_t)step * KB;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -829,12 +855,15 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
 
     int round = 0;
     int m0, n0, split;
-    int nsteps = point_at(0, m0, n0, split);               // grid <= total: every workgroup owns an item in round 0
+    int nsteps = item_of(0, m0, n0, split);                // grid <= total: every workgroup owns an item in round 0
+    point_A(0);
+    point_B(0);
     dmaA(0, 0);
+    if constexpr (A3) dmaA(1, 1);                          // launch guard: every item has >= 2 K-tiles
     dmaB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // K-tile 0 complete for everyone
-    int gbuf = 0;                                          // ring slot of the K-tile about to be consumed
+    __builtin_amdgcn_s_barrier();                          // K-tile 0 (and 1 of A) complete for everyone
+    int ia = 0, ib = 0;                                    // ring slots of the K-tile about to be consumed
 
     for (;;) {
         const bool have_next = round + 1 < my_rounds;
@@ -849,7 +878,6 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         // the accumulators are NOT cleared: the first k-substep of an item issues its MFMAs with C = 0 (mma32_first), which
         // saves TM x 32 v_mov per wave and item in the seam between two items
         f32x16 acc[TM][2];
-        constexpr bool USE_V2 = PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL;
         constexpr int AUX_EPI = USE_V2 ? EPI : PA_EPI_STORE;
         V2Aux<AUX_EPI, TM> aux;
         constexpr int AUXN = V2Aux<AUX_EPI, TM>::N;
@@ -858,13 +886,29 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         PA_PROBE_STAMP(round < 24, round * 16);
 
         for (int t = 0; t < nsteps; ++t) {
-            const char* sA = smem + gbuf * STAGE_BYTES;
-            const char* sB = sA + A_BYTES;
+            const char* sA = smem + G::a_off(ia);
+            const char* sB = smem + G::b_off(ib);
             const bool last = t + 1 == nsteps;
-            const bool more = !last || have_next;
-            // the K-tile fetched during this one: t+1 of this item, or tile 0 of the next item
-            if (last && have_next) point_at(round + 1, m0, n0, split);
-            const int dstep = last ? 0 : t + 1;
+            // requests made during this tile: B of tile t+1, A of tile t+PDA -- of this item, or the first tiles of the next
+            const bool fetchB = !last || have_next;
+            if (last && have_next) point_B(round + 1);
+            const int stepB = last ? 0 : t + 1;
+            const int ta = t + PDA;
+            const bool fetchA = ta < nsteps || have_next;
+            if (ta == nsteps && have_next) point_A(round + 1);
+            const int stepA = ta < nsteps ? ta : ta - nsteps;
+            int slotA = ia + PDA;
+            if (slotA >= NA) slotA -= NA;
+            // loads this wave may leave in flight at the end of the tile (vmcnt retires in issue order, so the youngest
+            // ones are named by their count): with A3 the A request of tile t+2, and in the item's last tile the
+            // epilogue's auxiliary rows.  Issue order within the tile: B, then A, then aux.
+            const int tail = (A3 && fetchA ? A_PER : 0) + (USE_V2 && AUXN > 0 && last ? AUXN : 0);
+            auto wait_tile = [&]() {
+                if (tail == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (tail == A_PER) wait_vmcnt<A_PER>();
+                else if (tail == AUXN) wait_vmcnt<(AUXN > 0 ? AUXN : 1)>();
+                else wait_vmcnt<A_PER + AUXN>();
+            };
             // PA_NT_SUBSTEPS 16-wide k-substeps per L / M segment pair (1: 8 barriers per K-tile, 2: 4)
             constexpr int SUB = PA_NT_SUBSTEPS, NPH = 4 / SUB;
 #pragma unroll
@@ -879,19 +923,20 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
 #pragma unroll
                     for (int j = 0; j < 2; ++j) fb[u][j] = *(const typename Frag<T>::type*)(sB + offB + j * 32 * 128 + coff);
                 }
-                if (more) {      // the whole next K-tile is requested at least one full segment pair before it is waited for
-                    if (ph == 0) dmaA(gbuf ^ 1, dstep);
-                    if (ph == (NPH == 4 ? 1 : 0)) dmaB(gbuf ^ 1, dstep);
+                // the next K-tile(s) are requested at least one full segment pair before they are waited for
+                if constexpr (A3) {
+                    if (ph == 0 && fetchB) dmaB(ib ^ 1, stepB);
+                    if (ph == (NPH == 4 ? 1 : 0) && fetchA) dmaA(slotA, stepA);
+                } else {
+                    if (ph == 0 && fetchA) dmaA(slotA, stepA);
+                    if (ph == (NPH == 4 ? 1 : 0) && fetchB) dmaB(ib ^ 1, stepB);
                 }
-                // last K-tile of the item: request the first auxiliary rows of its epilogue now, AFTER this tile's LDS-DMA
-                // (vmcnt retires in issue order -- tests/probes/probe_store.hip -- so the end-of-tile wait below can leave
-                // exactly these AUXN youngest loads in flight: they land under the remaining MFMAs)
+                // last K-tile of the item: request the first auxiliary rows of its epilogue now, AFTER this tile's LDS-DMA:
+                // they land under the remaining MFMAs
                 if constexpr (USE_V2 && AUXN > 0) {
                     if (last && ph == NPH / 2) aux.issue(a, cur_m0, cur_n0, wr, wc, lane);
                 }
-                if (ph == NPH - 1 && wr == 1) {
-                    if (USE_V2 && AUXN > 0 && last) wait_vmcnt<AUXN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (ph == NPH - 1 && wr == 1) wait_tile();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -920,19 +965,27 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                             for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (ph == NPH - 1 && wr == 0) {
-                    if (USE_V2 && AUXN > 0 && last) wait_vmcnt<AUXN>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (ph == NPH - 1 && wr == 0) wait_tile();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
-            gbuf ^= 1;
+            if (++ia == NA) ia = 0;
+            ib ^= 1;
             PA_PROBE_STAMP(round < 24 && t < 13, round * 16 + 1 + t);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();         // re-align the two groups: every fragment read is done
-        // slabs go into the ring slot that was read last (gbuf now names the one holding the next item's tile 0)
-        float* slab = (float*)(wave < G::SLABS_IN_STAGE ? smem + (gbuf ^ 1) * STAGE_BYTES + wave * SLAB_BYTES
-                                                        : smem + 2 * STAGE_BYTES + (wave - G::SLABS_IN_STAGE) * SLAB_BYTES);
+        // slabs go into the ring slots that were read last (ia / ib now name the ones holding the next item's tile 0)
+        const int freeA = ia == 0 ? NA - 1 : ia - 1, freeB = ib ^ 1;
+        char* slab_c;
+        if constexpr (A3) {
+            slab_c = wave < G::SLABS_A ? smem + G::a_off(freeA) + wave * 8192
+                     : wave < G::SLABS_A + G::SLABS_B ? smem + G::b_off(freeB) + (wave - G::SLABS_A) * 8192
+                                                      : smem + G::RING + (wave - G::SLABS_A - G::SLABS_B) * 8192;
+        } else {
+            slab_c = wave < G::SLABS_IN_STAGE ? smem + G::a_off(freeA) + wave * SLAB_BYTES
+                                              : smem + G::RING + (wave - G::SLABS_IN_STAGE) * SLAB_BYTES;
+        }
+        float* slab = (float*)slab_c;
         if (PA_PROBE_FLAG(a, 1)) {             // probe: no epilogue at all (accumulators kept live)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -940,7 +993,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-        } else if constexpr (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL) {
+        } else if constexpr (USE_V2) {
             // straight-line epilogue; matrix edges are handled by the buffer descriptors (launch_gemm_stagger keeps the
             // row-remapped patch-embedding form and matrices >= 2 GiB away from this kernel)
             const float* brow = HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr;
@@ -973,17 +1026,19 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         }
 #endif
         if (!have_next) break;
-        // (re)derive the DMA cursor of the item just started: cheaper than carrying it through the epilogue
+        // (re)derive the DMA cursors of the item just started: cheaper than carrying them through the epilogue
         ++round;
-        nsteps = point_at(round, m0, n0, split);
+        nsteps = item_of(round, m0, n0, split);
+        point_A(round);
+        point_B(round);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // slabs are dead: the slot may be refilled by the DMA
+        __builtin_amdgcn_s_barrier();                      // slabs are dead: the slots may be refilled by the DMA
     }
 }
 
-template <typename T, int EPI, int TM>
+template <typename T, int EPI, int TM, bool A3 = false>
 static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
-    using G = StaggerGeom<TM>;
+    using G = StaggerGeom<TM, A3>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     const int tiles_m = (int)cdiv(a.M, 64 * TM), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
@@ -997,20 +1052,26 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     const int64_t lim = (int64_t)1 << 31;
     const bool big = (int64_t)a.M * a.ldolp * 2 >= lim || (int64_t)a.M * a.ldolp2 * 2 >= lim || (int64_t)a.M * a.ldaux * 2 >= lim ||
                      (int64_t)a.M * a.ldr * 4 >= lim || (int64_t)a.M * a.ldo32 * 4 >= lim;
-    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps || cdiv(total, 256) > G::MAX_ROUNDS ||
+    if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps ||
         (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && (big || (EPI == PA_EPI_RESID && a.row_mod > 0))))
         return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+    if constexpr (A3) {      // two K-tiles of lead need two K-tiles in every item; the short item table bounds the rounds
+        if (ksteps - (splits - 1) * per < 2 || per < 2 || cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_stagger<T, EPI, TM, false>(a, st);
+    } else {
+        if (cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+    }
 #ifdef PA_PROBE
     constexpr int LDS_BYTES = G::LDS + 2 * PROBE_SLOTS * 8;
 #else
     constexpr int LDS_BYTES = G::LDS;
 #endif
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (probe build)");
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM>,
+        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
                        tiles_n, nwg, per, total);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
@@ -1032,6 +1093,7 @@ static int pick_nt_variant(int M, int N, int K) {
     };
     int best = 1;
     double best_cost = 1e30;
+    // (r02: 192-row A3 tiles instead of 256-row ones for the N = 3072 GEMMs: fc1+GELU -2 %, dgrad-fc2 +5 % in the step: kept)
     for (const Cand& c : cands) {
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         const double rounds = (double)cdiv(tiles, c.slots);
@@ -1047,7 +1109,10 @@ template <typename T, int EPI>
 static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
     if constexpr (sizeof(T) == 4) return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // parity mode: one variant
     else {
-        const int v = a.tune ? a.tune : pick_nt_variant(a.M, a.N, a.K);
+        int v = a.tune ? a.tune : pick_nt_variant(a.M, a.N, a.K);
+        // the 192- / 128-row role-split tiles run with the A operand two K-tiles ahead (A3) unless PA_NT_A3=0 (A/B knob)
+        static const bool a3 = [] { const char* e = getenv("PA_NT_A3"); return !e || atoi(e) != 0; }();
+        if (!a.tune && a3 && EPI != PA_EPI_PARTIAL && (v == 7 || v == 8)) v += 10;
         switch (v) {
             case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
             case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
@@ -1056,6 +1121,8 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
             case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
             case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
             case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split
+            case 17: return launch_gemm_stagger<T, EPI, 3, true>(a, st);   // 192x256 role-split, A two K-tiles ahead (3 A slots)
+            case 18: return launch_gemm_stagger<T, EPI, 2, true>(a, st);   // 128x256 role-split, A two K-tiles ahead
         }
         return PA_EINVAL;
     }
@@ -1231,10 +1298,23 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int ms, int cbase, 
 }
 
 // one work item: output tile `tile_id` (already XCD-remapped) of problem `a`, K slice `split`
+// r02: THREE stages of 48 tokens (144 KiB) instead of two of 64, every stage requested TWO stages ahead: both operands
+// are activations that come from HBM in the training step, and one stage of lead (~1.4 us) is less than a loaded HBM
+// round trip (the same effect cost the K = 2304 / 3072 NT GEMMs 15 %: profiles/r02_instep_vs_isolated.json).
+static constexpr int TN_ROWS = PA_TN_STEP_ROWS;          // tokens per stage (host code sizes the K slices in these units)
+#ifndef PA_TN_STAGES
+#define PA_TN_STAGES 3         // (A/B: -DPA_TN_STEP_ROWS=64 -DPA_TN_STAGES=2 is the r01 pipeline)
+#endif
+static constexpr int TN_STAGES = PA_TN_STAGES;
+static constexpr int TN_OP_BYTES = TN_ROWS * 512, TN_STAGE_BYTES = 2 * TN_OP_BYTES;     // 24 KiB per operand, 48 KiB per stage
+static constexpr int TN_LDS = TN_STAGES * TN_STAGE_BYTES;                               // 144 KiB
+static_assert(TN_ROWS % 16 == 0 && TN_ROWS * 512 % (8 * 1024) == 0, "whole 16-token phases, whole 1 KiB pieces per wave");
+
 __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int split,
                                                      const int steps_per_split) {
-    constexpr int TM = 4, WN = 4, MROWS = 64;
-    constexpr int OP_BYTES = MROWS * 512, STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB per operand, 64 KiB per stage
+    constexpr int TM = 4, WN = 4, MROWS = TN_ROWS, NPH = MROWS / 16;
+    constexpr int OP_BYTES = TN_OP_BYTES, STAGE_BYTES = TN_STAGE_BYTES;
+    constexpr int PER = OP_BYTES / 1024 / 8;               // LDS-DMA pieces per wave, operand and stage: 3
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1247,14 +1327,14 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     const int st_begin = split * steps_per_split;
     const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
 
-    // this wave's 4 + 4 LDS-DMA pieces per stage: piece q = wave*4+i covers tile rows 2q, 2q+1 (512 B each).
-    // Source address = uniform base of the stage (SGPRs, advanced by 64 token rows per stage) + a per-lane
+    // this wave's PER + PER LDS-DMA pieces per stage: piece q = wave*PER+i covers tile rows 2q, 2q+1 (512 B each).
+    // Source address = uniform base of the stage (SGPRs, advanced by MROWS token rows per stage) + a per-lane
     // 32-bit offset fixed for the whole kernel: no 64-bit vector arithmetic in the K loop.
-    uint32_t voffA[4], voffB[4];
-    int rowin[4];
+    uint32_t voffA[PER], voffB[PER];
+    int rowin[PER];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave * 4 + i;
+    for (int i = 0; i < PER; ++i) {
+        const int q = wave * PER + i;
         const int row = q * 2 + (lane >> 5);
         const int pc = lane & 31;
         const int c = pc ^ ((row & 3) << 2);
@@ -1264,25 +1344,25 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     }
     const char* baseA = (const char*)a.A + (int64_t)st_begin * MROWS * a.lda * 2;
     const char* baseB = (const char*)a.B + (int64_t)st_begin * MROWS * a.ldb * 2;
-    auto dma = [&](const char* base, int ld, const uint32_t (&voff)[4], char* dst, int step) {
+    auto dma = [&](const char* base, int ld, const uint32_t (&voff)[PER], char* dst, int step) {
         const char* sb = base + (int64_t)step * MROWS * ld * 2;              // uniform
         const int valid = Mtok - (st_begin + step) * MROWS;                  // token rows that exist in this stage
         if (valid >= MROWS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < PER; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         } else {   // last stage of the last split: rows past the end re-read the last token (zeroed by zero_tail)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PER; ++i) {
                 const uint32_t back = (uint32_t)max(rowin[i] - (valid - 1), 0) * (uint32_t)ld * 2u;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (voff[i] - back)),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
             }
         }
     };
-    auto dmaA = [&](int buf, int step) { dma(baseA, a.lda, voffA, smem + buf * STAGE_BYTES + wave * 4096, step); };
-    auto dmaB = [&](int buf, int step) { dma(baseB, a.ldb, voffB, smem + buf * STAGE_BYTES + OP_BYTES + wave * 4096, step); };
+    auto dmaA = [&](int buf, int step) { dma(baseA, a.lda, voffA, smem + buf * STAGE_BYTES + wave * (PER * 1024), step); };
+    auto dmaB = [&](int buf, int step) { dma(baseB, a.ldb, voffB, smem + buf * STAGE_BYTES + OP_BYTES + wave * (PER * 1024), step); };
     // token rows beyond Mtok (last stage only) were filled from a clamped row: zero what THIS wave staged,
     // after its DMA landed and before the barrier that publishes the stage
     auto zero_tail = [&](int buf, int step) {
@@ -1290,9 +1370,9 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         if (valid >= MROWS) return;
         char* sA = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             if (rowin[i] >= valid) {
-                const int off = (wave * 4 + i) * 1024 + lane * 16;
+                const int off = (wave * PER + i) * 1024 + lane * 16;
                 *(uint4*)(sA + off) = make_uint4(0, 0, 0, 0);
                 *(uint4*)(sA + OP_BYTES + off) = make_uint4(0, 0, 0, 0);
             }
@@ -1310,6 +1390,7 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     }
 
     if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
+    if (TN_STAGES > 2 && nsteps > 1) { dmaA(1, 1); dmaB(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (nsteps > 0) zero_tail(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1341,9 +1422,19 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         return f;
     };
 
+    constexpr int LEAD = TN_STAGES - 1; // stages of lead of the requests (2; 1 in the two-stage A/B build)
+    int slot = 0;                       // ring slot of stage t;  stage t+LEAD goes into the slot stage t-1 just left
     for (int t = 0; t < nsteps; ++t) {
-        const uint32_t sb = (t & 1) * STAGE_BYTES;
-        const bool more = t + 1 < nsteps;
+        const uint32_t sb = slot * STAGE_BYTES;
+        const bool more = t + 1 < nsteps, more2 = t + LEAD < nsteps;
+        const int slot1 = slot == TN_STAGES - 1 ? 0 : slot + 1;
+        const int slot2 = LEAD == 1 ? slot1 : (slot1 == TN_STAGES - 1 ? 0 : slot1 + 1);
+        // end of the stage: stage t+1 (requested during stage t-1) must have landed; the 2*PER pieces of stage t+2, the
+        // youngest in this wave's queue, may stay in flight (vmcnt retires in issue order)
+        auto wait_stage = [&]() {
+            if (LEAD > 1 && more2) wait_vmcnt<2 * PER>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) zero_tail(slot1, t + 1);
+        };
         auto phase = [&](auto phc) {
             constexpr int ph = decltype(phc)::value;
             // ---------------- L segment: fragments of 16 tokens ----------------
@@ -1354,14 +1445,11 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 fb[j] = join(lds_tr16_asm<ph * 8192>(offB[j] + sb), lds_tr16_asm<ph * 8192 + 2048>(offB[j] + sb));
-            if (more) {
-                if (ph == 0) dmaA((t + 1) & 1, t + 1);
-                if (ph == 1) dmaB((t + 1) & 1, t + 1);
+            if (more2) {
+                if (ph == 0) dmaA(slot2, t + LEAD);
+                if (ph == 1) dmaB(slot2, t + LEAD);
             }
-            if (ph == 3 && wr == 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (more) zero_tail((t + 1) & 1, t + 1);
-            }
+            if (ph == NPH - 1 && wr == 1) wait_stage();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1379,9 +1467,8 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
                     for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
             }
             __builtin_amdgcn_s_setprio(0);
-            if (ph == 3 && wr == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (more) zero_tail((t + 1) & 1, t + 1);
+            if (ph == NPH - 1 && wr == 0) {
+                wait_stage();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1390,7 +1477,9 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
         phase(std::integral_constant<int, 2>{});
-        phase(std::integral_constant<int, 3>{});
+        if constexpr (NPH == 4) phase(std::integral_constant<int, 3>{});
+        static_assert(NPH == 3 || NPH == 4, "three or four 16-token phases per stage");
+        slot = slot1;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, split, wr, wc, lane);
@@ -1422,10 +1511,10 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBa
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
-    constexpr int LDS = 2 * 2 * 64 * 512;   // 128 KiB
+    constexpr int LDS = TN_LDS;
     const int tiles_m = (int)cdiv(a.M, 256), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
-    const int steps = (int)cdiv(a.K, 64);
+    const int steps = (int)cdiv(a.K, TN_ROWS);
     const int per = (int)cdiv(steps, a.split_k);
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_tn_stagger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1754,6 +1843,8 @@ extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, 
     return check_launch();
 }
 
+extern "C" int pa_gemm_tn_step_rows(void) { return TN_ROWS; }
+
 extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->out_f32 || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->split_k < 1) return PA_EINVAL;
     if (a->epilogue != PA_EPI_PARTIAL) return PA_EUNSUPPORTED;
@@ -1779,13 +1870,13 @@ extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
         pb->a[p] = x;
         pb->tiles_n[p] = (int)cdiv(x.N, 256);
         pb->nwg[p] = (int)cdiv(x.M, 256) * pb->tiles_n[p];
-        pb->per[p] = (int)cdiv(cdiv(x.K, 64), x.split_k);
+        pb->per[p] = (int)cdiv(cdiv(x.K, TN_ROWS), x.split_k);
         pb->first[p] = total;
         total += pb->nwg[p] * x.split_k;
     }
     pb->first[n] = total;
     pb->n = n;
-    constexpr int LDS = 2 * 2 * 64 * 512;
+    constexpr int LDS = TN_LDS;
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_tn_stagger_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS) == hipSuccess;

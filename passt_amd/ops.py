@@ -61,6 +61,7 @@ def _p(t, dtype=None, strided=False):
 # bench.py sets this to a dict to time every GEMM launch with HIP events on the launch stream:
 # {epilogue: [(start_event, end_event, algorithmic_flops)]}
 GEMM_PROFILE = None
+PROFILE_BY_SHAPE = bool(os.environ.get("PASST_AMD_PROFILE_BY_SHAPE"))     # bench.py per_epilogue keyed by (epilogue, M, N, K)
 GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
 GEMM_RESERVED = 0      # pa_gemm_args.reserved (ignored by the product library; probe builds: tools/probe_epilogue.py)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
@@ -201,7 +202,8 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     ev0.record()
     check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
     ev1.record()
-    GEMM_PROFILE.setdefault(_EPI_NAME[epilogue], []).append((ev0, ev1, 2.0 * a.M * a.N * a.K))
+    kind = _EPI_NAME[epilogue] if not PROFILE_BY_SHAPE else f"{_EPI_NAME[epilogue]}_M{a.M}_N{a.N}_K{a.K}"
+    GEMM_PROFILE.setdefault(kind, []).append((ev0, ev1, 2.0 * a.M * a.N * a.K))
 
 
 def gemm_colsum_ws(M, N, device, ws=None):
@@ -259,6 +261,12 @@ def wgrad(dY_t, X_t, out_f32, dtype, accumulate=False, partial_ws=None):
     return partial_ws
 
 
+def tn_step_rows():
+    """PA_TN_STEP_ROWS of the loaded library: tokens per pipeline stage of the bf16 role-split TN kernel."""
+    return _lib.load().pa_gemm_tn_step_rows()
+
+
+
 def pick_split_k_slots(tiles, steps, slots=256):
     """split count for the one-workgroup-per-CU kernels: fill whole rounds of `slots` workgroups
     (tile quantisation), at least 8 reduction steps per slice, prefer fewer slices on ties."""
@@ -287,7 +295,7 @@ def pick_batched_splits(probs, slots=256):
 
 def _pick_batched_splits(probs, slots=256):
     """probs: [(tiles, k_steps)] of the problems sharing one launch.  Every work item is one 256x256 tile x one K slice of
-    L steps (S_p = ceil(steps_p / L)).  Cost model (us, MI355X measurements): rounds x (L + 3) x 1.6 for the K loops and
+    L steps of 48 tokens (S_p = ceil(steps_p / L)).  Cost model (us, MI355X measurements): rounds x (L + 4) x 1.2 for the K loops and
     per-item epilogues, with rounds = ceil(#items / slots), plus 0.05 per item for the f32 partial slab it writes and the
     reduction reads back (256 KiB each way; about half of it hides under the K loops -- calibrated on the passt_s block:
     7 slices beat 2 and 4, run 82)."""
@@ -296,7 +304,7 @@ def _pick_batched_splits(probs, slots=256):
         S = [max(1, min(64, -(-st // L))) for _, st in probs]
         items = sum(t * s_ for (t, _), s_ in zip(probs, S))
         per = max(-(-st // s_) for (_, st), s_ in zip(probs, S))
-        cost = -(-items // slots) * (per + 3) * 1.6 + items * 0.05
+        cost = -(-items // slots) * (per + 4) * 1.2 + items * 0.05        # 48-token steps: ~1.2 us each, ~4.8 us fixed per item
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = S, cost
     return best if best is not None else [1] * len(probs)
@@ -308,7 +316,7 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     K = X.shape[1]
     if dtype == PA_BF16 and GEMM_TUNE != 1:      # role-split 256x256 kernel, one workgroup per CU
         tiles = ((N + 255) // 256) * ((K + 255) // 256)
-        S = pick_split_k_slots(tiles, (Mtok + 63) // 64)
+        S = pick_split_k_slots(tiles, (Mtok + tn_step_rows() - 1) // tn_step_rows())
     else:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         mrows = 64 if dtype == PA_BF16 else 32
@@ -347,7 +355,8 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
     for dY, X, out, acc in problems:
         Mtok, N = dY.shape
         metas.append((Mtok, N, X.shape[1]))
-    splits = pick_batched_splits([(((N + 255) // 256) * ((K + 255) // 256), (Mtok + 63) // 64) for Mtok, N, K in metas])
+    splits = pick_batched_splits([(((N + 255) // 256) * ((K + 255) // 256), (Mtok + tn_step_rows() - 1) // tn_step_rows())
+                                  for Mtok, N, K in metas])
     need = sum(S * m[1] * m[2] for S, m in zip(splits, metas))
     if partial_ws is None or partial_ws.numel() < need:
         partial_ws = torch.empty(need, device=problems[0][0].device, dtype=torch.float32)

@@ -60,7 +60,7 @@ def test_gemm_store_bias(dt, M, N, K):
     assert e < tol(dt), e
 
 
-@pytest.mark.parametrize("tune", [0, 1, 2, 3, 6, 7, 8, 9])
+@pytest.mark.parametrize("tune", [0, 1, 2, 3, 6, 7, 8, 9, 17, 18])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (300, 264, 128), (2 * 474, 2304, 256)])
 def test_gemm_tile_variants(tune, M, N, K):
     """every workgroup-tile / pipeline variant of pa_gemm_nt (pa_gemm_args.tune) computes the same GEMM"""
@@ -441,7 +441,7 @@ def test_staged_cache_batched_refresh_matches_single():
 
 
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
-@pytest.mark.parametrize("tune", [0, 1, 6, 7, 8])
+@pytest.mark.parametrize("tune", [0, 1, 6, 7, 8, 17, 18])
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (2 * 474, 3072, 768), (1000, 768, 256)])
 def test_gemm_dgelu_fused_bias_gradient(dt, tune, M, N, K):
     """EPI_DGELU can return the column sums of its output (the fc1.bias gradient) from the same epilogue."""
@@ -506,7 +506,7 @@ def test_wave_augment_matches_reference_pipeline():
     assert float((wave[:, 0].cpu() - torch.from_numpy(ref)).abs().max()) < 5e-7
 
 
-@pytest.mark.parametrize("tune", [0, 6, 7, 8])
+@pytest.mark.parametrize("tune", [0, 6, 7, 8, 17, 18])
 @pytest.mark.parametrize("M,N,K", [(1, 8, 64), (33, 40, 64), (255, 256, 64), (257, 264, 128), (5000, 8, 192),
                                    (70000, 264, 64), (3 * 474, 2304, 768)])
 def test_persistent_gemm_edge_shapes(tune, M, N, K):
