@@ -229,7 +229,8 @@ int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumul
  * ------------------------------------------------------------------------------------------ */
 int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                      float scale, int dtype, void* stream);
-/* dqkv[B*N][3*H*64] from d_o[B*nq][H*64]; lse from the forward; delta: f32 workspace [B*H*nq].  The K and V thirds
+/* dqkv[B*N][3*H*64] from d_o[B*nq][H*64]; lse from the forward; delta: f32 workspace [2*B*H*nq] (per-query
+ * scalars the dQ kernel hands to the dK/dV kernel: rowsum(dO*O)*scale, then -lse*log2 e).  The K and V thirds
  * of dqkv are written for all N tokens, the Q third only for rows q < nq (the caller zeroes the rest: pa_zero2d). */
 int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
                      const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DKDV_WAVES : 1))) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ d_o, int ldo,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            const float* __restrict__ ws, int64_t plane,
                                                             T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         char* sb = smem + buf * STAGE;
         stage_tile<T>(sb, base, ldqkv, qt * TROWS, N, wave, lane);
         stage_tile<T>(sb + Tile<T>::BYTES, dobase, ldo, qt * TROWS, nq, wave, lane);
-        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), lse + (int64_t)bh * nq, qt * TROWS, nq, lane);
-        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, delta + (int64_t)bh * nq, qt * TROWS, nq, lane);
+        // both per-query scalars come pre-scaled from the dQ kernel's workspace: -lse*log2(e) and delta*scale
+        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), ws + plane + (int64_t)bh * nq, qt * TROWS, nq, lane);
+        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, ws + (int64_t)bh * nq, qt * TROWS, nq, lane);
     };
     stage(0, 0);
     for (int qt = 0; qt < ntiles; ++qt) {
@@ -354,23 +355,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 mma32<T>(dpa, row_frag<T>(sDO, qb * 32 + (lane & 31), st, lane), vf[st]);
             }
 #pragma unroll
-#if !PA_ATTN_PK
-            for (int r = 0; r < 16; ++r) {
-                const int ql = qb * 32 + acc_row(r, lane);
-                const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -sLse[ql] * LOG2E));
-                sa[r] = p;
-                dpa[r] = p * (dpa[r] - sDelta[ql]) * scale;
+            for (int g = 0; g < 4; ++g) {                       // accumulator rows 4g..4g+3 are 4 consecutive queries
+                const int ql = qb * 32 + 8 * g + 4 * (lane >> 5);
+                const f32x4 nl = *(const f32x4*)(sLse + ql), dl = *(const f32x4*)(sDelta + ql);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, nl[e]));
+                    sa[r] = p;
+                    dpa[r] = p * fmaf(dpa[r], scale, -dl[e]);
+                }
             }
-#else
-            for (int r = 0; r < 16; r += 2) {                   // rows r, r+1 of the accumulator are consecutive queries
-                const int ql = qb * 32 + acc_row(r, lane);
-                const f32x2 l2 = f32x2{sLse[ql], sLse[ql + 1]} * pk_splat(-LOG2E);
-                const f32x2 p = exp2_2(pk_fma(f32x2{sa[r], sa[r + 1]}, pk_splat(sl2), l2));
-                const f32x2 ds = p * (f32x2{dpa[r], dpa[r + 1]} - f32x2{sDelta[ql], sDelta[ql + 1]}) * pk_splat(scale);
-                sa[r] = p[0]; sa[r + 1] = p[1];               // P
-                dpa[r] = ds[0]; dpa[r + 1] = ds[1];           // dS
-            }
-#endif
             // queries beyond nq exist only in the last tile (uniform branch); lanes whose own key is beyond
             // N only produce their own, never stored, outputs and need no mask
             if (qt == ntiles - 1 && (nq & (TROWS - 1))) {
@@ -423,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DQ_WAVES : 1))) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
-                                                          const float* __restrict__ lse, float* __restrict__ delta,
+                                                          const float* __restrict__ lse, float* __restrict__ delta, int64_t plane,
                                                           T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -458,7 +453,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             for (int e = 0; e < Tile<T>::EPC; ++e) dlt = fmaf((float)dof[s][e], (float)of[e], dlt);
         }
         dlt += __shfl_xor(dlt, 32, 64);
-        if (lane < 32 && q < nq) delta[(int64_t)bh * nq + q] = dlt;
+        // workspace for the dK/dV kernel, already in the form its inner loop consumes: delta*scale, -lse*log2(e)
+        if (lane < 32 && q < nq) {
+            delta[(int64_t)bh * nq + q] = dlt * scale;
+            delta[plane + (int64_t)bh * nq + q] = -lse2;
+        }
     }
     f32x16 dq[2];
 #pragma unroll
@@ -556,15 +555,17 @@ static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* 
 template <typename T>
 static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo, const float* lse,
                            float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq, float scale, hipStream_t st) {
-    // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+    // dQ first: it also fills the workspace the dK/dV kernel consumes, two planes of B*H*nq floats:
+    // rowsum(dO * O) * scale and -lse * log2(e)
+    const int64_t plane = (int64_t)B * H * nq;
     dim3 gridq((unsigned)cdiv(nq, 128), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, gridq, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (const T*)o,
-                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
+                       (const T*)d_o, ldo, lse, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale);
     int rc = check_launch();
     if (rc) return rc;
     dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
-                       (const T*)d_o, ldo, lse, delta, (T*)dqkv, lddqkv, H, N, nq, scale);
+                       (const T*)d_o, ldo, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale);
     return check_launch();
 }
 

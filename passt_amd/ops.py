@@ -427,7 +427,7 @@ def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None):
     dtype = PA_DTYPE[qkv.dtype]
     nq = N if nq is None else nq
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
+    delta = torch.empty(2 * lse.numel(), device=lse.device, dtype=torch.float32)
     lib = _lib.load()
     if nq < N:
         es = qkv.element_size()
