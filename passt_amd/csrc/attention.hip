@@ -155,16 +155,34 @@ static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Workgroup -> (block of 128 queries / keys, sequence x head).  The blocks of one head read the same K / V (resp. Q /
+// dO) panels, 121 KB per head: they only share them through an L2 if they run on the same XCD, and the dispatcher
+// deals consecutive workgroup ids round-robin over the 8 XCDs.  So the grid is one-dimensional and id L is read as
+// XCD x = L & 7, slot s = L >> 3: head = x + 8 * (s / nblk), block = s % nblk -- the nblk blocks of a head are
+// consecutive slots of ONE XCD.  (With the (block, head) grid they sat on nblk different XCDs and every block
+// re-fetched the panels over the fabric: FETCH_SIZE 393 MB per forward launch for 187 MB of operands,
+// profiles/r02_pmc_fetch_run_r04.txt.)
+__device__ __forceinline__ bool attn_block(int nblk, int BH, int& blk, int& bh) {
+    const int L = blockIdx.x, s = L >> 3;
+    const int g = s / nblk;
+    blk = s - g * nblk;
+    bh = (L & 7) + 8 * g;
+    return bh < BH;
+}
+static inline unsigned attn_grid(int nblk, int BH) { return (unsigned)(nblk * 8 * ((BH + 7) / 8)); }
+
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_FWD_WAVES : 2))) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
-                                                       int ldo, float* __restrict__ lse, int H, int N, int nq, float scale) {
+                                                       int ldo, float* __restrict__ lse, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    int blk, bh;
+    if (!attn_block(nblk, BH, blk, bh)) return;
+    const int b = bh / H, h = bh % H;
     const int D = H * HD;
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;      // q of token 0 of this (b,h)
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk * 128 + wave * 32;
     const int qrow = min(q0 + (lane & 31), N - 1);
 
     typename Frag<T>::type qf[Tile<T>::NFRAG];
@@ -294,15 +312,17 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DKDV_WAVES : 1))) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ d_o, int ldo,
                                                             const float* __restrict__ ws, int64_t plane,
-                                                            T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
+                                                            T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    int blk, bh;
+    if (!attn_block(nblk, BH, blk, bh)) return;
+    const int b = bh / H, h = bh % H;
     const int D = H * HD;
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
     const T* dobase = d_o + (int64_t)b * nq * ldo + h * HD;     // d_o / lse / delta: nq rows per sequence
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = blk * 128 + wave * 32;
     const int key = k0 + (lane & 31);
     const int krow = min(key, N - 1);
     const bool active = k0 < N;                                 // wave-uniform
@@ -419,15 +439,17 @@ template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DQ_WAVES : 1))) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
                                                           const float* __restrict__ lse, float* __restrict__ delta, int64_t plane,
-                                                          T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale) {
+                                                          T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    int blk, bh;
+    if (!attn_block(nblk, BH, blk, bh)) return;
+    const int b = bh / H, h = bh % H;
     const int D = H * HD;
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
     const T* dobase = d_o + (int64_t)b * nq * ldo + h * HD;     // d_o / lse / delta: nq rows per sequence
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blk * 128 + wave * 32;
     const int q = q0 + (lane & 31);
     const int qrow = min(q, nq - 1);
     const bool active = q0 < nq;                                // wave-uniform
@@ -547,8 +569,9 @@ template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * (2 
 template <typename T>
 static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                            float scale, hipStream_t st) {
-    dim3 grid((unsigned)cdiv(nq, 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, nq, scale);
+    const int nblk = (int)cdiv(nq, 128);
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(attn_grid(nblk, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o,
+                       ldo, lse, H, N, nq, scale, nblk, B * H);
     return check_launch();
 }
 
@@ -558,14 +581,13 @@ static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void
     // dQ first: it also fills the workspace the dK/dV kernel consumes, two planes of B*H*nq floats:
     // rowsum(dO * O) * scale and -lse * log2(e)
     const int64_t plane = (int64_t)B * H * nq;
-    dim3 gridq((unsigned)cdiv(nq, 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, gridq, dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (const T*)o,
-                       (const T*)d_o, ldo, lse, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale);
+    const int nblkq = (int)cdiv(nq, 128), nblkk = (int)cdiv(N, 128);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(attn_grid(nblkq, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
+                       (const T*)o, (const T*)d_o, ldo, lse, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale, nblkq, B * H);
     int rc = check_launch();
     if (rc) return rc;
-    dim3 grid((unsigned)cdiv(N, 128), (unsigned)(B * H));
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, grid, dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
-                       (const T*)d_o, ldo, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(attn_grid(nblkk, B * H)), dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
+                       (const T*)d_o, ldo, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale, nblkk, B * H);
     return check_launch();
 }
 
