@@ -159,7 +159,9 @@ typedef struct {
                             * (benchmarking / autotuning), pa_gemm_nt bf16: 1 = 128x128 tile, 4 waves, 2 workgroups/CU;
                             * 2 = 256x256 lockstep; 6 / 7 / 8 = role-split 256x256 / 192x256 / 128x256 (8 waves,
                             * staggered wave groups); 9 = 128x256, 4 waves, 64-byte stages, 2 workgroups/CU (slower: DESIGN.md 4.1).
-                            * pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256. */
+                            * 17 / 18 = 7 / 8 with three A slots (A requested two K-tiles ahead; what 0 picks for them).
+                            * pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256.  pa_gemm_tn_batched: tune of the
+                            * FIRST problem = 2 orders the work items problem-major instead of slice-major (A/B only). */
     /* PA_EPI_DGELU only, optional: colsum_out[n] = (colsum_accumulate ? colsum_out[n] : 0) + sum_m out[m][n] (of the
      * f32 values, before rounding) -- the bias gradient of the Linear whose pre-activation is `aux` (fc1.bias),
      * reduced inside the epilogue instead of by a separate pass over out_lp.  colsum_ws: f32 workspace of
@@ -178,7 +180,8 @@ int pa_gemm_tn(const pa_gemm_args* a, void* stream);
 /* Up to PA_TN_BATCH_MAX bf16 weight-gradient problems in ONE launch (e.g. the four Linears of a transformer block,
  * once all their operands exist): the work items of all problems share one grid, so there is no drain / prologue
  * between problems and items of different length pack onto the CUs.  Same arguments and results as n calls of
- * pa_gemm_tn; `a` is a HOST array. */
+ * pa_gemm_tn; `a` is a HOST array.  When all problems use the same split_k the items are dealt slice-major with
+ * every XCD owning a contiguous run, so the tiles sharing a dY / X panel of a token slice share an L2. */
 #define PA_TN_BATCH_MAX 4
 /* tokens the bf16 role-split weight-gradient kernel consumes per pipeline stage: a K slice of pa_gemm_tn /
  * pa_gemm_tn_batched is ceil(ceil(K / PA_TN_STEP_ROWS) / split_k) such steps (callers sizing split_k use it) */

@@ -1497,12 +1497,26 @@ struct TnBatch {
     pa_gemm_args a[PA_TN_BATCH_MAX];
     int32_t first[PA_TN_BATCH_MAX + 1];      // first work item of problem p; first[n] = total
     int32_t tiles_n[PA_TN_BATCH_MAX], nwg[PA_TN_BATCH_MAX], per[PA_TN_BATCH_MAX];
-    int32_t n;
+    int32_t tfirst[PA_TN_BATCH_MAX + 1];     // first tile of problem p in the slice-major order (order = 1)
+    int32_t n, order;
 };
 __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBatch b) {
-    // (r02: dealing the items slice-major so that an XCD's ~32 resident workgroups share one token slice -- every dY / X
-    // panel stage fetched once per XCD -- measured 3-4 % SLOWER than this problem-major order, 374 vs 360 us per launch:
-    // the kernel is not bound by the fabric)
+    // Item order (b.order = 1, the default whenever all problems use the same slice count): slice-major over the whole
+    // batch, every XCD owning a contiguous run of that order (xcd_swizzle over all items), so an XCD's ~32 resident
+    // workgroups work on one token slice and the tiles that share a dY or an X panel find its stages in their own L2:
+    // L2->fabric reads 1 984 -> 962 MB per launch for 746 MB of operands (rocprofv3 FETCH_SIZE, run r04c), launch
+    // 336 -> 335 us in the step.  (With the two-stage kernel of round 1 the same order measured 3-4 % slower and was
+    // rejected; with three stages in flight it is no longer behind.)  b.order = 0 (tune = 2 on the first problem, A/B
+    // only): problem-major, the tiles of one (problem, slice) spread over the XCDs.
+    if (b.order == 1) {
+        const int logical = xcd_swizzle(blockIdx.x, b.first[b.n]);
+        const int tiles_all = b.tfirst[b.n];
+        const int split = logical / tiles_all;
+        int t = logical - split * tiles_all, p = 0;
+        while (p + 1 < b.n && t >= b.tfirst[p + 1]) ++p;
+        gemm_tn_stagger_item(b.a[p], b.tiles_n[p], t - b.tfirst[p], split, b.per[p]);
+        return;
+    }
     int p = 0;
     while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
     const int item = blockIdx.x - b.first[p];
@@ -1861,7 +1875,8 @@ extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
     if (!a || n < 1 || n > PA_TN_BATCH_MAX) return PA_EINVAL;
     TnBatch batch;
     TnBatch* pb = &batch;
-    int total = 0;
+    int total = 0, tiles = 0;
+    bool same_split = true;
     for (int p = 0; p < n; ++p) {
         const pa_gemm_args& x = a[p];
         if (!x.A || !x.B || !x.out_f32 || x.M <= 0 || x.N <= 0 || x.K <= 0 || x.split_k < 1) return PA_EINVAL;
@@ -1872,10 +1887,15 @@ extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
         pb->nwg[p] = (int)cdiv(x.M, 256) * pb->tiles_n[p];
         pb->per[p] = (int)cdiv(cdiv(x.K, TN_ROWS), x.split_k);
         pb->first[p] = total;
+        pb->tfirst[p] = tiles;
         total += pb->nwg[p] * x.split_k;
+        tiles += pb->nwg[p];
+        same_split = same_split && x.split_k == a[0].split_k;
     }
     pb->first[n] = total;
+    pb->tfirst[n] = tiles;
     pb->n = n;
+    pb->order = (a[0].tune != 2 && same_split) ? 1 : 0;
     constexpr int LDS = TN_LDS;
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_tn_stagger_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -63,6 +63,7 @@ def _p(t, dtype=None, strided=False):
 GEMM_PROFILE = None
 PROFILE_BY_SHAPE = bool(os.environ.get("PASST_AMD_PROFILE_BY_SHAPE"))     # bench.py per_epilogue keyed by (epilogue, M, N, K)
 GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
+TN_BATCH_ORDER = int(os.environ.get("PASST_AMD_TN_ORDER", "0"))   # 2: problem-major item order (A/B only, see gemm.hip)
 GEMM_RESERVED = 0      # pa_gemm_args.reserved (ignored by the product library; probe builds: tools/probe_epilogue.py)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
 
@@ -371,7 +372,7 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
         a.lda, a.ldb = dY.stride(0), X.stride(0)
         a.A, a.B = _p(dY, dtype, True), _p(X, dtype, True)
         a.out_f32, a.ldo32 = _p(part), K
-        a.split_k, a.tune = S, 0
+        a.split_k, a.tune = S, TN_BATCH_ORDER
         r.partial, r.out, r.n, r.splits, r.accumulate = _p(part), _p(out, torch.float32), N * K, S, int(acc)
         flops += 2.0 * N * K * Mtok
     lib = _lib.load()
