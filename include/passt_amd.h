@@ -175,7 +175,12 @@ int64_t pa_gemm_colsum_ws_floats(int M, int N);
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
 /* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major
  * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over
- * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic). */
+ * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic).
+ * Optional (bf16 role-split kernel only, i.e. tune != 1): colsum_ws != NULL asks for the column sums of A as well --
+ * colsum_ws[split_k][a->M] partial sums over each slice's tokens (the bias gradient of the Linear whose output
+ * gradient is A: nn.Linear, models/passt.py:345), computed by one extra MFMA per phase in the tiles of the first
+ * B-column block instead of a separate pass over A; finish with pa_reduce_partials(colsum_ws, split_k, a->M, ...).
+ * colsum_out / colsum_accumulate are ignored here. */
 int pa_gemm_tn(const pa_gemm_args* a, void* stream);
 /* Up to PA_TN_BATCH_MAX bf16 weight-gradient problems in ONE launch (e.g. the four Linears of a transformer block,
  * once all their operands exist): the work items of all problems share one grid, so there is no drain / prologue

@@ -1310,8 +1310,16 @@ static constexpr int TN_OP_BYTES = TN_ROWS * 512, TN_STAGE_BYTES = 2 * TN_OP_BYT
 static constexpr int TN_LDS = TN_STAGES * TN_STAGE_BYTES;                               // 144 KiB
 static_assert(TN_ROWS % 16 == 0 && TN_ROWS * 512 % (8 * 1024) == 0, "whole 16-token phases, whole 1 KiB pieces per wave");
 
+// CSUM (tiles of X-column block 0 of a problem with colsum_ws set): every wave also sums ONE of its four dY fragments
+// over the tokens with a ninth MFMA per phase against a fragment of ones -- wave (wr, wc) owns dY columns
+// wr*128 + wc*32 + [0,32), so the eight waves cover the tile's 256 dY columns once -- and the slice's column sums of dY
+// (= the partial bias gradient) leave with the partial slab.  Replaces a separate pass over dY (qkv.bias: 186 MB read
+// per block) by +1/8 MFMA work in 1/12 of the work items.
+// (CSUM is a wave-uniform run-time flag, not a template parameter: a second copy of the item would double a kernel that
+// is already ~50 KB of code, and the instruction cache is 64 KB per two CUs.)
 __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int split,
                                                      const int steps_per_split) {
+    const bool CSUM = a.colsum_ws != nullptr && tile_id % tiles_n == 0;
     constexpr int TM = 4, WN = 4, MROWS = TN_ROWS, NPH = MROWS / 16;
     constexpr int OP_BYTES = TN_OP_BYTES, STAGE_BYTES = TN_STAGE_BYTES;
     constexpr int PER = OP_BYTES / 1024 / 8;               // LDS-DMA pieces per wave, operand and stage: 3
@@ -1388,6 +1396,12 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
+    f32x16 accb;                       // CSUM only
+    bf16x8 ones;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     if (nsteps > 0) { dmaA(0, 0); dmaB(0, 0); }
     if (TN_STAGES > 2 && nsteps > 1) { dmaA(1, 1); dmaB(1, 1); }
@@ -1400,7 +1414,7 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     // per-lane fragment addresses inside a stage (see tn2_frag: the +4-row partner is +2048 bytes, a 16-token
     // phase +8192, and the swizzle term only depends on the lane)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    uint32_t offA[TM], offB[2];
+    uint32_t offA[TM], offB[2], offCS;
     {
         const int p = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
         const int r1 = h * 8 + (p >> 2);
@@ -1408,6 +1422,10 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         for (int i = 0; i < TM; ++i) {
             const int col = wr * 128 + i * 32 + g * 16 + (p & 3) * 4;
             offA[i] = lds0 + tn2_swz(r1, col >> 3) + (col & 7) * 2;
+        }
+        {
+            const int col = wr * 128 + wc * 32 + g * 16 + (p & 3) * 4;
+            offCS = lds0 + tn2_swz(r1, col >> 3) + (col & 7) * 2;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1445,6 +1463,8 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 fb[j] = join(lds_tr16_asm<ph * 8192>(offB[j] + sb), lds_tr16_asm<ph * 8192 + 2048>(offB[j] + sb));
+            bf16x8 fcs = ones;       // CSUM: this wave's own copy of dY row-block wc (fa[wc] would be a run-time register index)
+            if (CSUM) fcs = join(lds_tr16_asm<ph * 8192>(offCS + sb), lds_tr16_asm<ph * 8192 + 2048>(offCS + sb));
             if (more2) {
                 if (ph == 0) dmaA(slot2, t + LEAD);
                 if (ph == 1) dmaB(slot2, t + LEAD);
@@ -1466,6 +1486,12 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
 #pragma unroll
                     for (int j = 0; j < 2; ++j) mma32<bf16>(acc[i][j], fa[i], fb[j]);
             }
+            // CSUM is wave-uniform: a scalar branch around one MFMA.  Inline asm with the accumulator tied: through the
+            // builtin the register allocator gave the conditional MFMA a fresh destination and moved 16 registers back
+            // behind MFMA-latency s_nops inside the barrier-paced segment (+20 % on the whole launch).  The s_nop is the
+            // VALU-write -> MFMA-read wait the compiler inserts for its own MFMAs (it re-materialises `ones` with v_movs
+            // right in front of the asm and cannot know the asm is an MFMA).
+            if (CSUM) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(fcs), "v"(ones));
             __builtin_amdgcn_s_setprio(0);
             if (ph == NPH - 1 && wr == 0) {
                 wait_stage();
@@ -1483,6 +1509,16 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, split, wr, wc, lane);
+    if (CSUM) {                        // every column of the 32x32 block holds the same sums: lanes 0 and 32 write them
+        if ((lane & 31) == 0) {
+            float* dst = a.colsum_ws + (int64_t)split * a.M;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 128 + wc * 32 + acc_row(r, lane);
+                if (m < a.M) dst[m] = accb[r];
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
@@ -1508,20 +1544,21 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBa
     // 336 -> 335 us in the step.  (With the two-stage kernel of round 1 the same order measured 3-4 % slower and was
     // rejected; with three stages in flight it is no longer behind.)  b.order = 0 (tune = 2 on the first problem, A/B
     // only): problem-major, the tiles of one (problem, slice) spread over the XCDs.
+    int p = 0, t, split;
     if (b.order == 1) {
         const int logical = xcd_swizzle(blockIdx.x, b.first[b.n]);
         const int tiles_all = b.tfirst[b.n];
-        const int split = logical / tiles_all;
-        int t = logical - split * tiles_all, p = 0;
+        split = logical / tiles_all;
+        t = logical - split * tiles_all;
         while (p + 1 < b.n && t >= b.tfirst[p + 1]) ++p;
-        gemm_tn_stagger_item(b.a[p], b.tiles_n[p], t - b.tfirst[p], split, b.per[p]);
-        return;
+        t -= b.tfirst[p];
+    } else {
+        while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+        const int item = blockIdx.x - b.first[p];
+        split = item / b.nwg[p];
+        t = xcd_swizzle(item - split * b.nwg[p], b.nwg[p]);
     }
-    int p = 0;
-    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
-    const int item = blockIdx.x - b.first[p];
-    const int split = item / b.nwg[p], t = item - split * b.nwg[p];
-    gemm_tn_stagger_item(b.a[p], b.tiles_n[p], xcd_swizzle(t, b.nwg[p]), split, b.per[p]);
+    gemm_tn_stagger_item(b.a[p], b.tiles_n[p], t, split, b.per[p]);
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
@@ -1866,6 +1903,7 @@ extern "C" int pa_gemm_tn(const pa_gemm_args* a, void* stream) {
     if ((a->lda * es) % 16 || (a->ldb * es) % 16 || a->ldo32 % 4) return PA_EUNSUPPORTED;
     if (a->M < (int)(16 / es) || a->N < (int)(16 / es) || a->N % 8 || a->M % (int)(16 / es)) return PA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (a->colsum_ws && (a->dtype != PA_BF16 || a->tune == 1)) return PA_EUNSUPPORTED;    // only the role-split kernel sums dY
     if (a->dtype == PA_BF16) return a->tune == 1 ? launch_gemm_tn<bf16>(*a, st) : launch_gemm_tn_stagger(*a, st);
     if (a->dtype == PA_F32) return launch_gemm_tn<float>(*a, st);
     return PA_EINVAL;

@@ -348,23 +348,26 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
 
 
 def wgrad_tn_batched(problems, dtype, partial_ws=None):
-    """problems: up to 4 of (dY [M][N], X [M][K], out [N][K] f32, accumulate): all weight gradients of a block in ONE
-    pa_gemm_tn_batched launch + ONE batched split-K reduction.  Returns the (possibly grown) partial workspace."""
+    """problems: up to 4 of (dY [M][N], X [M][K], out [N][K] f32, accumulate[, db [N] f32 or None]): all weight gradients of a
+    block in ONE pa_gemm_tn_batched launch + ONE batched split-K reduction.  A problem with db also gets its bias gradient
+    (column sums of dY) out of the same launch.  Returns the (possibly grown) partial workspace."""
     from ._lib import ReduceDesc
     assert dtype == PA_BF16 and 1 <= len(problems) <= 4
+    problems = [tuple(p) + (None,) * (5 - len(p)) for p in problems]
     metas = []
-    for dY, X, out, acc in problems:
+    for dY, X, out, acc, db in problems:
         Mtok, N = dY.shape
         metas.append((Mtok, N, X.shape[1]))
     splits = pick_batched_splits([(((N + 255) // 256) * ((K + 255) // 256), (Mtok + tn_step_rows() - 1) // tn_step_rows())
                                   for Mtok, N, K in metas])
-    need = sum(S * m[1] * m[2] for S, m in zip(splits, metas))
+    need = sum(S * m[1] * (m[2] + (1 if p[4] is not None else 0)) for S, m, p in zip(splits, metas, problems))
     if partial_ws is None or partial_ws.numel() < need:
         partial_ws = torch.empty(need, device=problems[0][0].device, dtype=torch.float32)
+    nred = len(problems) + sum(1 for p in problems if p[4] is not None)
     args = (GemmArgs * len(problems))()
-    red = (ReduceDesc * len(problems))()
-    off, flops = 0, 0.0
-    for a, r, (dY, X, out, acc), (Mtok, N, K), S in zip(args, red, problems, metas, splits):
+    red = (ReduceDesc * nred)()
+    off, flops, k = 0, 0.0, len(problems)
+    for a, r, (dY, X, out, acc, db), (Mtok, N, K), S in zip(args, red, problems, metas, splits):
         part = partial_ws[off:off + S * N * K]
         off += S * N * K
         a.dtype, a.epilogue = dtype, EPI_PARTIAL
@@ -374,6 +377,13 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
         a.out_f32, a.ldo32 = _p(part), K
         a.split_k, a.tune = S, TN_BATCH_ORDER
         r.partial, r.out, r.n, r.splits, r.accumulate = _p(part), _p(out, torch.float32), N * K, S, int(acc)
+        if db is not None:              # bias partials [S][N] behind the weight partials; one more slab set to reduce
+            bpart = partial_ws[off:off + S * N]
+            off += S * N
+            a.colsum_ws = _p(bpart)
+            rb = red[k]
+            k += 1
+            rb.partial, rb.out, rb.n, rb.splits, rb.accumulate = _p(bpart), _p(db, torch.float32), N, S, int(acc)
         flops += 2.0 * N * K * Mtok
     lib = _lib.load()
     if GEMM_PROFILE is None:
@@ -384,7 +394,7 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
         check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
         ev1.record()
         GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, flops))
-    check(lib.pa_reduce_partials_batched(red, len(problems), _stream()), "pa_reduce_partials_batched")
+    check(lib.pa_reduce_partials_batched(red, nred, _stream()), "pa_reduce_partials_batched")
     return partial_ws
 
 

@@ -361,14 +361,16 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     def wgrad(dY, X, dW, db, done=None):
         if pending is None:
             return wgrad_async(dY, X, dW, db, done)
-        pending.append((dY, X, dW.view(dY.shape[1], -1), False))
-        if db is not None and done is None:
+        # the block's last problem (qkv) gets its bias gradient out of the batched launch itself (a ninth MFMA per phase
+        # in the tiles of the first X-column block); earlier ones with a bias (compact fc2 of the last block) use the
+        # column-sum kernel right away
+        fused_bias = done is not None and db is not None and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
+        pending.append((dY, X, dW.view(dY.shape[1], -1), False, db if fused_bias else None))
+        if db is not None and not fused_bias:
             ops.colsum(dY, db)
         if done is not None:
             scratch["part"] = ops.wgrad_tn_batched(pending, dt, scratch.get("part"))
             pending.clear()
-            if db is not None:
-                ops.colsum(dY, db)          # right after the GEMM that just streamed dY through the cache
             if on_block_done:
                 on_block_done(done)
 

@@ -547,6 +547,33 @@ def test_persistent_gemm_edge_shapes(tune, M, N, K):
         ops.GEMM_TUNE = old
 
 
+@pytest.mark.parametrize("tokens", [1500, 130, 47, 2 * 474 + 5])
+def test_wgrad_tn_batched_fused_bias_gradient(tokens):
+    """A problem with db gets colsum(dY) from the batched launch (ninth MFMA per phase in the tiles of the first
+    X-column block): == the f64 column sums, for ragged token counts, dY widths that are not tile multiples, with and
+    without accumulation; the weight gradients are unchanged."""
+    dt = PA_BF16
+    shapes = [(tokens, 768, 768, False), (tokens, 2304, 768, True), (tokens, 776, 3072, True), (tokens, 3072, 264, False)]
+    probs, refs = [], []
+    for i, (M, N, K, with_b) in enumerate(shapes):
+        dY = rnd(M, N, seed=190 + i).to(TD[dt]).to(DEV)
+        X = rnd(M, K, seed=195 + i).to(TD[dt]).to(DEV)
+        acc = i == 2
+        out = torch.full((N, K), 0.25 if acc else 7.0, device=DEV)
+        db = torch.full((N,), 0.25 if acc else -3.0, device=DEV) if with_b else None
+        probs.append((dY, X, out, acc, db))
+        refs.append((dY.double().cpu().T @ X.double().cpu() + (0.25 if acc else 0.0),
+                     dY.double().cpu().sum(0) + (0.25 if acc else 0.0)))
+    ops.wgrad_tn_batched(probs, dt)
+    torch.cuda.synchronize()
+    for (dY, X, out, acc, db), (ref_w, ref_b) in zip(probs, refs):
+        assert rel_err(out, ref_w) < 3e-3
+        if db is not None:
+            err = (db.double().cpu() - ref_b).abs().max().item() / max(ref_b.abs().max().item(), 1e-6)
+            record(f"wgrad_tn_fused_bias_t{tokens}_n{dY.shape[1]}", err=err)
+            assert err < 1e-5          # f32 accumulation of exact bf16 values
+
+
 def test_wgrad_tn_batched_matches_single_launches():
     """pa_gemm_tn_batched + pa_reduce_partials_batched: four weight gradients (different shapes, one with only a few
     token rows, one accumulating) in one launch each == the per-problem path."""

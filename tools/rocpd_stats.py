@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel summary of a rocprofv3 run (rocpd sqlite database), small enough to commit under profiles/.
 
-    python tools/rocpd_stats.py <results.db> [--steps N] [--skip K] > stats.txt
+    python tools/rocpd_stats.py <results.db> [--steps N] [--skip K] [--sequence N] > stats.txt
 
 Kernel trace: calls, total ms (per step when --steps is given), average / min / max us, share.
 PMC runs (rocprofv3 --pmc ...): per kernel the mean of every collected counter per dispatch.
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--sequence", type=int, default=0, help="also list the last N dispatches in launch order")
     args = ap.parse_args()
     con = sqlite3.connect(args.db)
     rows = con.execute("select s.kernel_name, d.start, d.end, d.dispatch_id, d.grid_size_x, d.workgroup_size_x "
@@ -46,6 +47,11 @@ def main():
     print(f"{'kernel':72s} {'calls':>6s} {'ms' + ('/step' if args.steps else ''):>9s} {'avg us':>9s} {'min us':>9s} {'max us':>9s} {'%':>6s}")
     for tot, name, n, avg, mn, mx in stats[:args.top]:
         print(f"{short(name):72s} {n:6d} {tot / 1e6 / div:9.3f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100.0 * tot / tot_all:6.2f}")
+    if args.sequence:
+        print(f"\n# last {args.sequence} dispatches in launch order: start offset us, duration us, grid, kernel")
+        t0 = rows[-args.sequence][1] if len(rows) >= args.sequence else rows[0][1]
+        for name, st, en, did, gx, wx in rows[-args.sequence:]:
+            print(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.2f} {gx:9d} {short(name)}")
     # counters
     try:
         pm = con.execute("select s.kernel_name, p.name, count(*), sum(e.value) from rocpd_pmc_event e "
