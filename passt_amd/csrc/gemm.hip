@@ -41,8 +41,15 @@ static constexpr int PROBE_SLOTS = 512;
             ((unsigned long long*)(smem + G::LDS))[(wave >> 2) * PROBE_SLOTS + (idx)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define PA_PROBE_FLAG(a, bit) (((a).reserved >> (bit)) & 1)
+// the same for the weight-gradient kernel (stamps behind its 144 KiB of stages)
+#define PA_PROBE_STAMP_TN(cond, idx)                                                                          \
+    do {                                                                                                      \
+        if ((cond) && (wave & 3) == 0 && lane == 0 && (idx) < PROBE_SLOTS)                                    \
+            ((unsigned long long*)(smem + TN_LDS))[(wave >> 2) * PROBE_SLOTS + (idx)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define PA_PROBE_STAMP(cond, idx) do {} while (0)
+#define PA_PROBE_STAMP_TN(cond, idx) do {} while (0)
 #define PA_PROBE_FLAG(a, bit) 0
 #endif
 
@@ -1302,6 +1309,17 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int ms, int cbase, 
 // are activations that come from HBM in the training step, and one stage of lead (~1.4 us) is less than a loaded HBM
 // round trip (the same effect cost the K = 2304 / 3072 NT GEMMs 15 %: profiles/r02_instep_vs_isolated.json).
 static constexpr int TN_ROWS = PA_TN_STEP_ROWS;          // tokens per stage (host code sizes the K slices in these units)
+#ifndef PA_TN_FRAG_PIPE
+// Three schedules of the same work were measured in the step, same box, same call (profiles/r02_tn_loop_variants.json):
+//   0: role split, fragment reads in the L segment                                   355.9 us per block launch
+//   1: role split, fragment reads issued inside the previous M segment               360.9
+//   2: lockstep, software pipelined, counted lgkmcnt waits, 2 barriers per stage     368.0
+// although the probe timeline (tools/probe_tn.py) shows variant 0 spending as long in L (~300-cycle loaded LDS latency)
+// as in M.  The kernel is at the chip's power budget: the same MFMA + LDS + fabric work costs the same energy in any
+// order, and saved cycles come back as lower clock (MI355X_MICROARCH.md, DVFS give-back).  Isolated on uniform random
+// data the launch takes 521 us, in the step on real gradients 356: the clock follows the data's toggle rate.
+#define PA_TN_FRAG_PIPE 0
+#endif
 #ifndef PA_TN_STAGES
 #define PA_TN_STAGES 3         // (A/B: -DPA_TN_STEP_ROWS=64 -DPA_TN_STAGES=2 is the r01 pipeline)
 #endif
@@ -1385,6 +1403,7 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
                 *(uint4*)(sA + OP_BYTES + off) = make_uint4(0, 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // partial stage only: the zeros are in LDS before the barrier
     };
 
     f32x16 acc[TM][2];                 // started by the first token step's MFMAs (C = 0), cleared only for an empty slice
@@ -1409,7 +1428,9 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     if (nsteps > 0) zero_tail(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if PA_TN_FRAG_PIPE != 2
     if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+#endif
 
     // per-lane fragment addresses inside a stage (see tn2_frag: the +4-row partner is +2048 bytes, a 16-token
     // phase +8192, and the swizzle term only depends on the lane)
@@ -1440,6 +1461,180 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         return f;
     };
 
+#if PA_TN_FRAG_PIPE == 2
+    // Software-pipelined lockstep loop (r02).  The probe timeline of the role-split loop (tools/probe_tn.py) showed the L
+    // segment as long as the M segment: a loaded ds_read_b64_tr_b16 takes ~300 cycles to return and L ended with a wait for
+    // all twelve, so every barrier interval carried that latency; issuing the reads inside the previous M segment only
+    // moved the wait.  Here all eight waves run the same schedule:
+    //   * the fragments of phase p+1 are requested inside phase p, each one right after the last MFMA that reads its old
+    //     value has been issued (operands are read at issue, LDS data returns >= 64 cycles later): no second register set;
+    //   * MFMAs go column-major -- (0,0) (1,0) (2,0) (3,0) | fb0' | (0,1) fa0' (1,1) fa1' (2,1) fa2' (3,1) fa3' fb1' -- and
+    //     every MFMA waits only for ITS operands with a counted s_waitcnt lgkmcnt (LDS returns in issue order; the twelve
+    //     reads outstanding at a phase start are fb0 fa0 fa1 fa2 fa3 fb1): lgkmcnt(8) (6) (4) (2) | (2);
+    //   * no barrier per phase: B1 at the end of the second-to-last phase publishes stage t+1 (every wave waited for its
+    //     own DMA pieces first) because the last phase requests fragments of stage t+1; B2 at the end of the stage: every
+    //     wave has consumed all its reads of stage t's slot, so the DMA of stage t+3, requested in phases 0 / 1 of stage
+    //     t+1, may overwrite it.
+    // Two barriers per stage instead of six, no LDS drain anywhere, the two waves of a SIMD share the matrix pipe freely.
+    static_assert(TN_STAGES == 3, "two stages of DMA lead");
+    constexpr int LEAD = TN_STAGES - 1;
+    int slot = 0;
+    bf16x8 fa[TM], fb[2];
+    auto wait_lgkm = [](auto nc) { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(nc)::value) : "memory"); };
+    fb[0] = join(lds_tr16_asm<0>(offB[0]), lds_tr16_asm<2048>(offB[0]));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = join(lds_tr16_asm<0>(offA[i]), lds_tr16_asm<2048>(offA[i]));
+    fb[1] = join(lds_tr16_asm<0>(offB[1]), lds_tr16_asm<2048>(offB[1]));
+    for (int t = 0; t < nsteps; ++t) {
+        const uint32_t sb = slot * STAGE_BYTES;
+        const bool more = t + 1 < nsteps, more2 = t + LEAD < nsteps;
+        const int slot1 = slot == TN_STAGES - 1 ? 0 : slot + 1;
+        const int slot2 = slot1 == TN_STAGES - 1 ? 0 : slot1 + 1;
+        auto wait_stage = [&]() {      // stage t+1 landed; the 2*PER pieces of stage t+2 (younger) may stay in flight
+            if (more2) wait_vmcnt<2 * PER>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) zero_tail(slot1, t + 1);
+        };
+        auto phase = [&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            constexpr int NOFF = ph == NPH - 1 ? 0 : (ph + 1) * 8192;       // next phase: same stage, or phase 0 of stage t+1
+            const uint32_t nsb = ph == NPH - 1 ? (uint32_t)slot1 * STAGE_BYTES : sb;
+            if (more2) {
+                if (ph == 0) dmaA(slot2, t + LEAD);
+                if (ph == 1) dmaB(slot2, t + LEAD);
+            }
+            bf16x8 fcs = ones;       // CSUM items (1 in 12): own fragment of dY row-block wc, and a full LDS drain (simple)
+            if (CSUM) {
+                fcs = join(lds_tr16_asm<ph * 8192>(offCS + sb), lds_tr16_asm<ph * 8192 + 2048>(offCS + sb));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto msteps = [&](auto firstc) {
+                constexpr bool FIRST = decltype(firstc)::value;
+                auto mm = [&](int i, int j) {
+                    if constexpr (FIRST) mma32_first<bf16>(acc[i][j], fa[i], fb[j]); else mma32<bf16>(acc[i][j], fa[i], fb[j]);
+                };
+                wait_lgkm(std::integral_constant<int, 8>{}); __builtin_amdgcn_sched_barrier(0);
+                mm(0, 0); __builtin_amdgcn_sched_barrier(0);
+                wait_lgkm(std::integral_constant<int, 6>{}); __builtin_amdgcn_sched_barrier(0);
+                mm(1, 0); __builtin_amdgcn_sched_barrier(0);
+                wait_lgkm(std::integral_constant<int, 4>{}); __builtin_amdgcn_sched_barrier(0);
+                mm(2, 0); __builtin_amdgcn_sched_barrier(0);
+                wait_lgkm(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+                mm(3, 0); __builtin_amdgcn_sched_barrier(0);
+                fb[0] = join(lds_tr16_asm<NOFF>(offB[0] + nsb), lds_tr16_asm<NOFF + 2048>(offB[0] + nsb));
+                wait_lgkm(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    mm(i, 1); __builtin_amdgcn_sched_barrier(0);
+                    fa[i] = join(lds_tr16_asm<NOFF>(offA[i] + nsb), lds_tr16_asm<NOFF + 2048>(offA[i] + nsb));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fb[1] = join(lds_tr16_asm<NOFF>(offB[1] + nsb), lds_tr16_asm<NOFF + 2048>(offB[1] + nsb));
+            };
+            if (ph == 0 && t == 0) msteps(std::true_type{}); else msteps(std::false_type{});
+            if (CSUM) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(fcs), "v"(ones));
+            if (ph == NPH - 2) {           // B1: publish stage t+1 before anyone requests its fragments
+                wait_stage();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            if (ph == NPH - 1) {           // B2: every wave is through with its reads of stage t's slot
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 3);
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        if constexpr (NPH == 4) phase(std::integral_constant<int, 3>{});
+        static_assert(NPH == 3 || NPH == 4, "three or four 16-token phases per stage");
+        slot = slot1;
+    }
+#elif PA_TN_FRAG_PIPE == 1
+    // Fragment pipeline (r02): the 12 transpose reads of a phase are issued INSIDE the previous M segment, each fragment
+    // right after the last MFMA that reads its old value has been issued (operands are read at issue; the LDS data
+    // returns >= 64 cycles later), so they cost no registers and the L segment shrinks to DMA requests + the wait.
+    // ds_read_b64_tr_b16 only reaches its rate with several waves issuing (MI355X_MICROARCH.md, LDS): with the reads in
+    // the L segment only one wave per SIMD was issuing them and L (~12 reads) was longer than M (8 MFMAs).
+    // Consequence: the last phase of a stage reads the NEXT stage, so that stage is waited for / published one barrier
+    // earlier than before (group 0: in its last L segment; group 1, one barrier behind: after its second-to-last M).
+    static_assert(TN_STAGES == 3, "the fragment pipeline assumes two stages of lead");
+    constexpr int LEAD = TN_STAGES - 1;
+    int slot = 0;
+    bf16x8 fa[TM], fb[2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = join(lds_tr16_asm<0>(offA[i]), lds_tr16_asm<2048>(offA[i]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = join(lds_tr16_asm<0>(offB[j]), lds_tr16_asm<2048>(offB[j]));
+    for (int t = 0; t < nsteps; ++t) {
+        const uint32_t sb = slot * STAGE_BYTES;
+        const bool more = t + 1 < nsteps, more2 = t + LEAD < nsteps;
+        const int slot1 = slot == TN_STAGES - 1 ? 0 : slot + 1;
+        const int slot2 = slot1 == TN_STAGES - 1 ? 0 : slot1 + 1;
+        // stage t+1 (requested during stage t-1) must have landed; the 2*PER pieces of stage t+2, the youngest in this
+        // wave's queue, may stay in flight (vmcnt retires in issue order)
+        auto wait_stage = [&]() {
+            if (more2) wait_vmcnt<2 * PER>(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) zero_tail(slot1, t + 1);
+        };
+        auto phase = [&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            constexpr int NOFF = ph == NPH - 1 ? 0 : (ph + 1) * 8192;       // next phase: same stage, or phase 0 of stage t+1
+            const uint32_t nsb = ph == NPH - 1 ? (uint32_t)slot1 * STAGE_BYTES : sb;
+            // ---------------- L segment: DMA requests, (CSUM: own fragment), wait for the fragments ----------------
+            bf16x8 fcs = ones;       // CSUM: this wave's own copy of dY row-block wc (fa[wc] would be a run-time register index)
+            if (CSUM) fcs = join(lds_tr16_asm<ph * 8192>(offCS + sb), lds_tr16_asm<ph * 8192 + 2048>(offCS + sb));
+            if (more2) {
+                if (ph == 0) dmaA(slot2, t + LEAD);
+                if (ph == 1) dmaB(slot2, t + LEAD);
+            }
+            if (ph == NPH - 1 && wr == 0) wait_stage();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 1);
+            // ---------------- M segment: MFMAs, each fragment reloaded as soon as it is free ----------------
+            __builtin_amdgcn_s_setprio(1);
+            auto msteps = [&](auto firstc) {
+                constexpr bool FIRST = decltype(firstc)::value;
+                auto mm = [&](int i, int j) {
+                    if constexpr (FIRST) mma32_first<bf16>(acc[i][j], fa[i], fb[j]); else mma32<bf16>(acc[i][j], fa[i], fb[j]);
+                };
+#pragma unroll
+                for (int i = 0; i < TM - 1; ++i) {
+                    mm(i, 0);
+                    mm(i, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fa[i] = join(lds_tr16_asm<NOFF>(offA[i] + nsb), lds_tr16_asm<NOFF + 2048>(offA[i] + nsb));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mm(TM - 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fb[0] = join(lds_tr16_asm<NOFF>(offB[0] + nsb), lds_tr16_asm<NOFF + 2048>(offB[0] + nsb));
+                __builtin_amdgcn_sched_barrier(0);
+                mm(TM - 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                fa[TM - 1] = join(lds_tr16_asm<NOFF>(offA[TM - 1] + nsb), lds_tr16_asm<NOFF + 2048>(offA[TM - 1] + nsb));
+                fb[1] = join(lds_tr16_asm<NOFF>(offB[1] + nsb), lds_tr16_asm<NOFF + 2048>(offB[1] + nsb));
+            };
+            if (ph == 0 && t == 0) msteps(std::true_type{}); else msteps(std::false_type{});
+            if (CSUM) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(fcs), "v"(ones));
+            __builtin_amdgcn_s_setprio(0);
+            if (ph == NPH - 2 && wr == 1) wait_stage();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 3);
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        if constexpr (NPH == 4) phase(std::integral_constant<int, 3>{});
+        static_assert(NPH == 3 || NPH == 4, "three or four 16-token phases per stage");
+        slot = slot1;
+    }
+#else
     constexpr int LEAD = TN_STAGES - 1; // stages of lead of the requests (2; 1 in the two-stage A/B build)
     int slot = 0;                       // ring slot of stage t;  stage t+LEAD goes into the slot stage t-1 just left
     for (int t = 0; t < nsteps; ++t) {
@@ -1471,8 +1666,10 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
             }
             if (ph == NPH - 1 && wr == 1) wait_stage();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 1);
             // ---------------- M segment ----------------
             __builtin_amdgcn_s_setprio(1);
             if (ph == 0 && t == 0) {
@@ -1493,12 +1690,14 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
             // right in front of the asm and cannot know the asm is an MFMA).
             if (CSUM) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb) : "v"(fcs), "v"(ones));
             __builtin_amdgcn_s_setprio(0);
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 2);
             if (ph == NPH - 1 && wr == 0) {
                 wait_stage();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 3);
         };
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
@@ -1507,7 +1706,16 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         static_assert(NPH == 3 || NPH == 4, "three or four 16-token phases per stage");
         slot = slot1;
     }
+#endif
+#if PA_TN_FRAG_PIPE != 2
     if (wr == 0) __builtin_amdgcn_s_barrier();
+#endif
+#ifdef PA_PROBE
+    __syncthreads();
+    if (g_probe_buf && blockIdx.x < 8)
+        for (int i = tid; i < 2 * PROBE_SLOTS; i += 512)
+            g_probe_buf[(size_t)blockIdx.x * 2 * PROBE_SLOTS + i] = ((unsigned long long*)(smem + TN_LDS))[i];
+#endif
     gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, split, wr, wc, lane);
     if (CSUM) {                        // every column of the 32x32 block holds the same sums: lanes 0 and 32 write them
         if ((lane & 31) == 0) {
@@ -1562,7 +1770,11 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBa
 }
 
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
+#ifdef PA_PROBE
+    constexpr int LDS = TN_LDS + 2 * PROBE_SLOTS * 8;
+#else
     constexpr int LDS = TN_LDS;
+#endif
     const int tiles_m = (int)cdiv(a.M, 256), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
     const int steps = (int)cdiv(a.K, TN_ROWS);
@@ -1934,7 +2146,11 @@ extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
     pb->tfirst[n] = tiles;
     pb->n = n;
     pb->order = (a[0].tune != 2 && same_split) ? 1 : 0;
+#ifdef PA_PROBE
+    constexpr int LDS = TN_LDS + 2 * PROBE_SLOTS * 8;
+#else
     constexpr int LDS = TN_LDS;
+#endif
     static bool attr_set = [] {
         return hipFuncSetAttribute((const void*)gemm_tn_stagger_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS) == hipSuccess;
