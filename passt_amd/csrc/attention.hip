@@ -361,6 +361,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const float* sLse = (const float*)(sQ + 2 * Tile<T>::BYTES);
         const float* sDelta = sLse + TROWS;
         if (!active) continue;          // all 32 keys of this wave are past N: stage and meet barriers only
+        // (r02 experiment: software-pipelining the two 32-query blocks of a tile inside the wave -- products(0) | products(1) +
+        // softmax(0) | dV/dK(0) + softmax(1) | dV/dK(1), regions fenced with sched_barrier -- needs sa/dpa of both blocks live:
+        // 256 VGPRs + 64-80 B of scratch at 2 waves per SIMD, and measured 8 % SLOWER for the whole backward, 246 vs 227 us.)
         const bool half_tile = qt == ntiles - 1 && qt * TROWS + 32 >= nq;     // second 32 queries of the tile do not exist
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
