@@ -169,8 +169,16 @@ typedef struct {
     float* colsum_out;
     float* colsum_ws;
     int32_t colsum_accumulate;
-    int32_t reserved;
+    int32_t reserved;      /* flags: 0, or PA_GEMM_BLOCKED_PRE (bits 0..7 are ignored by the product library) */
 } pa_gemm_args;
+/* PA_EPI_GELU: out_lp (the pre-activation) is written, PA_EPI_DGELU: aux (the same tensor) is read, in the library's
+ * blocked layout instead of row-major -- 4 KiB blocks of 32 rows x 64 columns in MFMA accumulator order, which both
+ * epilogues move with contiguous 16-byte-per-lane accesses and no LDS transposition.  The buffer is opaque to the caller:
+ * pa_gemm_blocked_pre_elems(M, N) elements (rows padded to whole tiles), ldolp / ldaux ignored.  Only for shapes where
+ * pa_gemm_blocked_pre_ok(M, N, K) returns 1 (bf16, tune = 0); otherwise pa_gemm_nt returns PA_EUNSUPPORTED. */
+#define PA_GEMM_BLOCKED_PRE 0x100
+int pa_gemm_blocked_pre_ok(int M, int N, int K);
+int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
 /* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major

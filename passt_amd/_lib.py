@@ -55,6 +55,8 @@ SIGNATURES = {
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
     "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     "pa_gemm_colsum_ws_floats": (i64, [i32, i32]),
+    "pa_gemm_blocked_pre_ok": (i32, [i32, i32, i32]),
+    "pa_gemm_blocked_pre_elems": (i64, [i32, i32]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn_batched": (i32, [C.POINTER(GemmArgs), i32, vp]),
@@ -90,6 +92,7 @@ SIGNATURES = {
     "pa_comm_destroy": (i32, [vp]),
     "pa_comm_last_error": (C.c_char_p, []),
 }
+GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flag (include/passt_amd.h)
 COMM_ID_BYTES = 128
 
 _lib = None

@@ -336,13 +336,23 @@ __device__ __forceinline__ auto tile_rsrc(const void* origin, int64_t bytes) {
 }
 static constexpr uint32_t V2_OOB = 0x80000000u;     // a lane offset no descriptor of < 2 GiB contains
 
+// rows of the blocked pre-activation buffer: whole 256-row tiles, so every pass of every tile height has its block
+__host__ __device__ __forceinline__ int64_t blocked_pre_rows(int M) { return ((int64_t)M + 255) / 256 * 256; }
+
 // Auxiliary rows of an item's epilogue (DGELU: pre-activation, RESID: residual): descriptor + the row vectors requested
 // ahead of their use.  The kernel calls issue() DURING the last K-tile of the item (the first rows come from HBM, not from
 // a cache: requested at the start of the epilogue their ~2-3k-cycle latency was exposed once per item), the epilogue
 // consumes the slots and refills them.  issue() is unconditional and always emits V2Aux::N loads: the K loop's counted
 // vmcnt wait relies on that number (rows / columns outside the matrix fall outside the descriptor and read as 0).
-template <int EPI, int TM> struct V2Aux {
+// BLK (PA_GEMM_BLOCKED_PRE, GELU / DGELU only): the pre-activation tensor lives in the library's BLOCKED layout instead
+// of row-major: one 4 KiB block per 32-row x 64-column pass of a wave tile, holding the pass in the ACCUMULATOR layout
+// (block (R, C) at ((R * N/64) + C) * 4096 bytes; inside: [q = 0..3][lane][4 dwords], dword = rows {2k, 2k+1} of column
+// 32 j + (lane & 31) for j = q >> 1, k = 4 (q & 1) + dword).  fc1's epilogue stores it and the dgrad-fc2 epilogue loads it
+// with four 1 KiB-contiguous 16-byte-per-lane accesses per pass and NO LDS transposition on either side (nobody else
+// reads the pre-activation; both GEMMs have the same M x N and pass geometry whatever their tile height).
+template <int EPI, int TM, bool BLK = false> struct V2Aux {
     static constexpr bool X = EPI == PA_EPI_DGELU, R = EPI == PA_EPI_RESID;
+    uint32_t blk_base = 0, blk_pitch = 0;                 // BLK: byte offset of pass 0's block, bytes between passes
     static constexpr int PASSES = X ? (PA_V2_DEPTH_X < TM ? PA_V2_DEPTH_X : TM) : 0;                    // DGELU: 32-row passes in flight
     static constexpr int HALVES = R ? (PA_V2_DEPTH_R < TM ? 2 * PA_V2_DEPTH_R : 2 * TM) : 0;        // RESID: 16-row half passes
     static constexpr int N = X ? PASSES * 4 : HALVES * 4;                                           // loads per wave in issue()
@@ -354,7 +364,16 @@ template <int EPI, int TM> struct V2Aux {
         if constexpr (N > 0) {
             const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
             const bool exists = mb < a.M && nb < a.N;
-            if constexpr (X) {
+            if constexpr (X && BLK) {
+                const int cb = a.N >> 6;                                   // 64-column blocks per row of blocks
+                blk_pitch = (uint32_t)cb * 4096u;
+                blk_base = ((uint32_t)(mb >> 5) * (uint32_t)cb + (uint32_t)(nb >> 6)) * 4096u;
+                rs = tile_rsrc(a.aux, exists ? (int64_t)blocked_pre_rows(a.M) * a.N * 2 : 0);
+                vofs = (uint32_t)lane * 16u;
+                ld = 0;
+#pragma unroll
+                for (int i = 0; i < PASSES; ++i) load_pass(i, i);
+            } else if constexpr (X) {
                 ld = (uint32_t)a.ldaux * 2u;
                 rs = tile_rsrc((const char*)a.aux + ((int64_t)mb * a.ldaux + nb) * 2, exists ? ((int64_t)(a.M - mb - 1) * a.ldaux + (a.N - nb)) * 2 : 0);
                 const int g = lane & 7;
@@ -373,11 +392,17 @@ template <int EPI, int TM> struct V2Aux {
     }
     // DGELU: rows 2p, 2p+1 of task t (p = lane>>3 + 8t) of pass i  ->  v[slot*4 + t*2 + q]
     __device__ __forceinline__ void load_pass(int slot, int i) {
+        if constexpr (BLK) {       // blocked layout: the four 1 KiB quarters of pass i's block -> v[slot*4 + q]
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int q = 0; q < 4; ++q)
+                v[slot * 4 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)q * 1024u, blk_base + (uint32_t)i * blk_pitch, 0);
+        } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                v[slot * 4 + t * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(i * 32 + 16 * t + q) * ld, 0, 0);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    v[slot * 4 + t * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(i * 32 + 16 * t + q) * ld, 0, 0);
+        }
     }
     // RESID: rows it*4 + (lane>>4) of half pass hp  ->  v[slot*4 + it]
     __device__ __forceinline__ void load_half(int slot, int hp) {
@@ -386,9 +411,9 @@ template <int EPI, int TM> struct V2Aux {
     }
 };
 
-template <int EPI, int TM>
+template <int EPI, int TM, bool BLK = false>
 __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32x16 (&acc)[TM][2], char* slab, const float* bias_row,
-                                                      int m0, int n0, int wr, int wc, int lane, int colsum_row, V2Aux<EPI, TM>& aux) {
+                                                      int m0, int n0, int wr, int wc, int lane, int colsum_row, V2Aux<EPI, TM, BLK>& aux) {
     static_assert(EPI == PA_EPI_STORE || EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU, "bf16 outputs");
     const int h = lane >> 5, c = lane & 31;
     const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;          // uniform: origin of this wave's tile
@@ -423,14 +448,30 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
         ors2 = tile_rsrc((const char*)a.out_lp2 + ((int64_t)mb * a.ldolp2 + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp2 + (a.N - nb)) * 2);
         vo2 = colok ? (uint32_t)(2 * (lane >> 3)) * ld2b + (uint32_t)g * 16u : V2_OOB;
     }
-    constexpr int XD = V2Aux<EPI, TM>::PASSES > 0 ? V2Aux<EPI, TM>::PASSES : 1;
+    constexpr int XD = V2Aux<EPI, TM, BLK>::PASSES > 0 ? V2Aux<EPI, TM, BLK>::PASSES : 1;
     float csum[2] = {0.f, 0.f};
+    // BLK + GELU: the pre-activation goes out in the blocked layout (see V2Aux): descriptor over the whole buffer, block of
+    // pass i at bbase + i * bpitch, lane part lane * 16
+    auto brs = ors;
+    uint32_t bbase = 0, bpitch = 0;
+    if constexpr (BLK && EPI == PA_EPI_GELU) {
+        const int cb = a.N >> 6;
+        bpitch = (uint32_t)cb * 4096u;
+        bbase = ((uint32_t)(mb >> 5) * (uint32_t)cb + (uint32_t)(nb >> 6)) * 4096u;
+        brs = tile_rsrc(a.out_lp, (int64_t)blocked_pre_rows(a.M) * a.N * 2);
+    }
     // (r02: running the LDS round trip of pass i under the polynomial math of pass i+1 -- software pipelining by hand --
     // measured no faster, 15.3k vs 14.0k cycles per 256x256 GELU tile, and costs ~50 registers: the passes stay sequential)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __builtin_amdgcn_sched_barrier(0);       // keep the passes apart: hoisting every pass's math to the top spills
-        if constexpr (EPI == PA_EPI_DGELU) {
+        u32x4 xblk[4];                           // BLK + DGELU: the pass's pre-activations, already in the accumulator layout
+        if constexpr (EPI == PA_EPI_DGELU && BLK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xblk[q] = aux.v[(i % XD) * 4 + q];
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + XD < TM) aux.load_pass(i % XD, i + XD);
+        } else if constexpr (EPI == PA_EPI_DGELU) {
             // pre-activation rows -> pair dwords -> slab (two 16-byte writes per task) -> accumulator layout
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -451,13 +492,16 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
             for (int k = 0; k < 8; ++k) {
                 f32x2 v = {acc[i][j][2 * k] + b2[j], acc[i][j][2 * k + 1] + b2[j]};
                 if constexpr (EPI == PA_EPI_DGELU) {
-                    const uint32_t xw = *(const uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
+                    uint32_t xw;
+                    if constexpr (BLK) xw = xblk[j * 2 + (k >> 2)][k & 3];
+                    else xw = *(const uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
                     const f32x2 x = {__builtin_bit_cast(float, xw << 16), __builtin_bit_cast(float, xw & 0xffff0000u)};
                     v = v * (PA_PROBE_FLAG(a, 2) ? x : gelu_grad_fast2(x));
-                    csum[j] += v[0] + v[1];
-                    if (rows_left < 32) {        // last row tile of the matrix (uniform branch): rows >= M hold duplicates of row M-1
+                    if (rows_left >= 32) {
+                        csum[j] += v[0] + v[1];
+                    } else {                     // last row tile of the matrix (uniform branch): rows >= M hold duplicates of row M-1
                         const int row = 2 * ((k & 1) + 4 * (k >> 1) + 2 * h);
-                        csum[j] -= (row < rows_left ? 0.f : v[0]) + (row + 1 < rows_left ? 0.f : v[1]);
+                        csum[j] += (row < rows_left ? v[0] : 0.f) + (row + 1 < rows_left ? v[1] : 0.f);
                     }
                 }
                 pk[j][k] = cvt_pk_bf16(v[0], v[1]);
@@ -466,16 +510,24 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                     pk2[j][k] = cvt_pk_bf16(gl[0], gl[1]);
                 }
             }
+        if constexpr (BLK && EPI == PA_EPI_GELU) {       // pre-activation: straight from the registers, 4 x 1 KiB contiguous
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 d = {pk[q >> 1][4 * (q & 1)], pk[q >> 1][4 * (q & 1) + 1], pk[q >> 1][4 * (q & 1) + 2], pk[q >> 1][4 * (q & 1) + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(d, brs, (PA_PROBE_FLAG(a, 0) ? V2_OOB : (uint32_t)lane * 16u) + (uint32_t)q * 1024u,
+                                                       bbase + (uint32_t)i * bpitch, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                *(uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk[j][k];
+                if constexpr (!(BLK && EPI == PA_EPI_GELU)) *(uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk[j][k];
                 if constexpr (EPI == PA_EPI_GELU) *(uint32_t*)(wbase + 4096 + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256) = pk2[j][k];
             }
         // same-wave LDS accesses execute in order: no barrier between the writes and the reads
 #pragma unroll
-        for (int o = 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
+        for (int o = (BLK && EPI == PA_EPI_GELU) ? 1 : 0; o < (EPI == PA_EPI_GELU ? 2 : 1); ++o)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const u32x4 d0 = *(const u32x4*)(r0 + o * 4096 + t * 2048), d1 = *(const u32x4*)(r1 + o * 4096 + t * 2048);
@@ -763,7 +815,7 @@ template <int TM, bool A3> struct StaggerGeom {
     static constexpr int LDS = TAB_OFF + MAX_ROUNDS * 16;
 };
 
-template <typename T, int EPI, int TM, bool A3 = false>
+template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false>
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                               const int nwg, const int ksteps_per_split, const int total) {
     using G = StaggerGeom<TM, A3>;
@@ -886,8 +938,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         // saves TM x 32 v_mov per wave and item in the seam between two items
         f32x16 acc[TM][2];
         constexpr int AUX_EPI = USE_V2 ? EPI : PA_EPI_STORE;
-        V2Aux<AUX_EPI, TM> aux;
-        constexpr int AUXN = V2Aux<AUX_EPI, TM>::N;
+        V2Aux<AUX_EPI, TM, BLK> aux;
+        constexpr int AUXN = V2Aux<AUX_EPI, TM, BLK>::N;
         const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
         if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
         PA_PROBE_STAMP(round < 24, round * 16);
@@ -1005,7 +1057,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             // row-remapped patch-embedding form and matrices >= 2 GiB away from this kernel)
             const float* brow = HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr;
             if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, aux);
-            else gemm_epilogue_v2_bf16<EPI, TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr, aux);
+            else gemm_epilogue_v2_bf16<EPI, TM, BLK>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr, aux);
         } else if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
             (void)slab;
             gemm_epilogue_f32_direct<EPI, TM>(a, acc, HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr, cur_m0,
@@ -1043,7 +1095,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     }
 }
 
-template <typename T, int EPI, int TM, bool A3 = false>
+template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false>
 static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     using G = StaggerGeom<TM, A3>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
@@ -1061,11 +1113,11 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
                      (int64_t)a.M * a.ldr * 4 >= lim || (int64_t)a.M * a.ldo32 * 4 >= lim;
     if (ksteps < 1 || (int64_t)(splits - 1) * per >= ksteps ||
         (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && (big || (EPI == PA_EPI_RESID && a.row_mod > 0))))
-        return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+        return BLK ? PA_EUNSUPPORTED : launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);     // (the generic kernel has no blocked form)
     if constexpr (A3) {      // two K-tiles of lead need two K-tiles in every item; the short item table bounds the rounds
-        if (ksteps - (splits - 1) * per < 2 || per < 2 || cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_stagger<T, EPI, TM, false>(a, st);
+        if (ksteps - (splits - 1) * per < 2 || per < 2 || cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_stagger<T, EPI, TM, false, BLK>(a, st);
     } else {
-        if (cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
+        if (cdiv(total, 256) > G::MAX_ROUNDS) return BLK ? PA_EUNSUPPORTED : launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
     }
 #ifdef PA_PROBE
     constexpr int LDS_BYTES = G::LDS + 2 * PROBE_SLOTS * 8;
@@ -1074,11 +1126,11 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
 #endif
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (probe build)");
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3>,
+        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
                        tiles_n, nwg, per, total);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
@@ -1120,6 +1172,19 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
         // the 192- / 128-row role-split tiles run with the A operand two K-tiles ahead (A3) unless PA_NT_A3=0 (A/B knob)
         static const bool a3 = [] { const char* e = getenv("PA_NT_A3"); return !e || atoi(e) != 0; }();
         if (!a.tune && a3 && EPI != PA_EPI_PARTIAL && (v == 7 || v == 8)) v += 10;
+        if constexpr (EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU) {
+            if (a.reserved & PA_GEMM_BLOCKED_PRE) {      // blocked pre-activation: role-split kernels only (pa_gemm_blocked_pre_ok)
+                if (a.N % 64 || blocked_pre_rows(a.M) * a.N * 2 >= ((int64_t)1 << 31)) return PA_EUNSUPPORTED;
+                switch (v) {
+                    case 6: return launch_gemm_stagger<T, EPI, 4, false, true>(a, st);
+                    case 7: return launch_gemm_stagger<T, EPI, 3, false, true>(a, st);
+                    case 8: return launch_gemm_stagger<T, EPI, 2, false, true>(a, st);
+                    case 17: return launch_gemm_stagger<T, EPI, 3, true, true>(a, st);
+                    case 18: return launch_gemm_stagger<T, EPI, 2, true, true>(a, st);
+                }
+                return PA_EUNSUPPORTED;
+            }
+        }
         switch (v) {
             case 1: return launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);   // 128x128, 4 waves (64x64 each), 2-stage
             case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
@@ -2104,6 +2169,18 @@ extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, 
     if (!in || !out || R <= 0 || C <= 0) return PA_EINVAL;
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, in, R, C, ld, out, accumulate);
     return check_launch();
+}
+
+extern "C" int64_t pa_gemm_blocked_pre_elems(int M, int N) { return blocked_pre_rows(M) * N; }
+// 1 when pa_gemm_nt with tune = 0 runs the bf16 M x N x K GELU / DGELU GEMMs on a kernel that has the blocked form
+extern "C" int pa_gemm_blocked_pre_ok(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64 || blocked_pre_rows(M) * N * 2 >= ((int64_t)1 << 31)) return 0;
+    const int v = pick_nt_variant(M, N, K);
+    if (v != 6 && v != 7 && v != 8) return 0;
+    // the same conditions under which launch_gemm_stagger keeps the role-split kernel (no split-K here)
+    const int tm = v == 6 ? 4 : (v == 7 ? 3 : 2);
+    const int64_t tiles = cdiv(M, 64 * tm) * cdiv(N, 256);
+    return K / 64 >= 2 && cdiv(tiles, 256) <= 128;
 }
 
 extern "C" int pa_gemm_tn_step_rows(void) { return TN_ROWS; }

@@ -5,12 +5,13 @@ libpasst_amd.so and returns the output tensors it allocated (torch is the alloca
 No fallback: a non-CUDA tensor or a missing library raises.
 """
 import ctypes as C
+import functools
 import os
 
 import torch
 
 from . import _lib
-from ._lib import (EPI_DGELU, EPI_GELU, EPI_PARTIAL, EPI_RESID, EPI_STORE, PA_BF16, PA_F32,
+from ._lib import (GEMM_BLOCKED_PRE, EPI_DGELU, EPI_GELU, EPI_PARTIAL, EPI_RESID, EPI_STORE, PA_BF16, PA_F32,
                    GemmArgs, MelParams, check)
 
 TORCH_DTYPE = {PA_F32: torch.float32, PA_BF16: torch.bfloat16}
@@ -170,7 +171,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
 # ---- GEMM ------------------------------------------------------------------------------------
 def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
             out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None,
-            colsum_out=None, colsum_ws=None, colsum_accumulate=False):
+            colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0):
     """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h.  EPI_DGELU can also return the
     column sums of its output (colsum_out [N] f32; colsum_ws from gemm_colsum_ws)."""
     a = GemmArgs()
@@ -194,7 +195,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
     a.tune = GEMM_TUNE
-    a.reserved = GEMM_RESERVED
+    a.reserved = GEMM_RESERVED | flags
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
@@ -222,12 +223,44 @@ def linear(x_lp, W_lp, bias, dtype):
     return out
 
 
+class BlockedPre:
+    """The pre-activation of an MLP in the library's blocked layout (PA_GEMM_BLOCKED_PRE): opaque storage written by the
+    fc1 + GELU epilogue and read by the GELU' epilogue of the matching input-gradient GEMM, nothing else."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, shape
+
+
+@functools.lru_cache(maxsize=None)
+def blocked_pre_ok(M, N, K):
+    return (not GEMM_TUNE and not os.environ.get("PASST_AMD_NO_BLOCKED_PRE")
+            and bool(_lib.load().pa_gemm_blocked_pre_ok(M, N, K)))
+
+
 def linear_gelu(x_lp, W_lp, bias, dtype):
+    """(pre, act): act = gelu(x W^T + b) row-major; pre = x W^T + b, row-major or -- where the library has the blocked
+    form for this shape -- a BlockedPre that only dgelu_gemm() can consume."""
     M, N = x_lp.shape[0], W_lp.shape[0]
-    pre = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
     act = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+    if dtype == PA_BF16 and blocked_pre_ok(M, N, x_lp.shape[1]):
+        buf = torch.empty(_lib.load().pa_gemm_blocked_pre_elems(M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+        gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=buf.view(-1, N), out_lp2=act, flags=GEMM_BLOCKED_PRE)
+        return BlockedPre(buf, (M, N)), act
+    pre = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
     gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
     return pre, act
+
+
+def dgelu_gemm(dy_lp, Wt_lp, pre, dtype, colsum_out=None, colsum_ws=None):
+    """d_pre[M][N] = (dy Wt^T) * gelu'(pre): the input gradient of fc2 times the GELU derivative; pre as returned by
+    linear_gelu (row-major tensor or BlockedPre)."""
+    blocked = isinstance(pre, BlockedPre)
+    M, N = pre.shape
+    d_pre = torch.empty((M, N), device=dy_lp.device, dtype=TORCH_DTYPE[dtype])
+    gemm_nt(dy_lp, Wt_lp, dtype, EPI_DGELU, aux=pre.buf.view(-1, N) if blocked else pre, out_lp=d_pre,
+            colsum_out=colsum_out, colsum_ws=colsum_ws, flags=GEMM_BLOCKED_PRE if blocked else 0)
+    return d_pre
 
 
 def linear_resid(x_lp, W_lp, bias, resid_f32, dtype, out=None):

@@ -396,11 +396,10 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         # fc2.bias gradient = column sums of dx: already produced by the LayerNorm backward that made dx (the next
         # block's norm1) -- except for the last block, whose dx comes from the head
         wgrad(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"] if last else None)
-        d_pre = torch.empty_like(h_pre)
         # the fc1.bias gradient (column sums of d_pre) comes out of the same epilogue
-        cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(d_pre.shape[0], d_pre.shape[1], d_pre.device, scratch.get("colsum_ws"))
-        ops.gemm_nt(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), dt, EPI_DGELU, aux=h_pre, out_lp=d_pre,
-                    colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
+        cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(h_pre.shape[0], h_pre.shape[1], dx_lp.device, scratch.get("colsum_ws"))
+        d_pre = ops.dgelu_gemm(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), h_pre, dt,
+                               colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
         wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
         d_ln2 = torch.empty_like(ln2)
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)

@@ -547,6 +547,38 @@ def test_persistent_gemm_edge_shapes(tune, M, N, K):
         ops.GEMM_TUNE = old
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 3072, 768), (1999, 3072, 768), (30336, 3072, 768), (777, 1024, 256), (4000, 4096, 1024)])
+def test_blocked_pre_activation_equals_row_major(M, N, K):
+    """PA_GEMM_BLOCKED_PRE: fc1 + GELU writes the pre-activation in the blocked accumulator-order layout and the GELU'
+    epilogue of the input-gradient GEMM reads it back: activation, d_pre and the fused fc1.bias column sums are
+    BIT-identical to the row-major path (same arithmetic, only the storage of one intermediate differs)."""
+    dt = PA_BF16
+    if not ops.blocked_pre_ok(M, N, K):
+        pytest.skip("the library runs this shape on a kernel without the blocked form")
+    x = rnd(M, K, seed=31).to(TD[dt]).to(DEV)
+    W = (rnd(N, K, seed=32) * 0.05).to(TD[dt]).to(DEV)
+    b = rnd(N, seed=33).to(DEV)
+    dy = rnd(M, K, seed=34).to(TD[dt]).to(DEV)           # gradient wrt fc2's input has fc1's output shape: dy [M][K2] x Wt [N][K2]
+    Wt = (rnd(N, K, seed=35) * 0.05).to(TD[dt]).to(DEV)
+    pre_b, act_b = ops.linear_gelu(x, W, b, dt)
+    assert isinstance(pre_b, ops.BlockedPre)
+    pre_r = torch.empty((M, N), device=DEV, dtype=TD[dt])
+    act_r = torch.empty((M, N), device=DEV, dtype=TD[dt])
+    ops.gemm_nt(x, W, dt, EPI_GELU, bias=b, out_lp=pre_r, out_lp2=act_r)
+    assert torch.equal(act_b, act_r)
+    ws = ops.gemm_colsum_ws(M, N, DEV)
+    db_b, db_r = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    d_b = ops.dgelu_gemm(dy, Wt, pre_b, dt, colsum_out=db_b, colsum_ws=ws)
+    d_r = ops.dgelu_gemm(dy, Wt, pre_r, dt, colsum_out=db_r, colsum_ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(d_b, d_r)
+    assert torch.equal(db_b, db_r)
+    ref = (dy.double().cpu() @ Wt.double().cpu().T)
+    xp = pre_r.double().cpu()
+    ref = ref * (0.5 * (1 + torch.erf(xp / 2 ** 0.5)) + xp * torch.exp(-xp * xp / 2) / (2 * torch.pi) ** 0.5)
+    assert rel_err(d_b, ref) < 1.5e-2
+
+
 @pytest.mark.parametrize("tokens", [1500, 130, 47, 2 * 474 + 5])
 def test_wgrad_tn_batched_fused_bias_gradient(tokens):
     """A problem with db gets colsum(dY) from the batched launch (ninth MFMA per phase in the tiles of the first
