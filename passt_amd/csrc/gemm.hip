@@ -497,11 +497,12 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                     else xw = *(const uint32_t*)(wbase + j * 128 + ((k & 1) + 4 * (k >> 1)) * 256);
                     const f32x2 x = {__builtin_bit_cast(float, xw << 16), __builtin_bit_cast(float, xw & 0xffff0000u)};
                     v = v * (PA_PROBE_FLAG(a, 2) ? x : gelu_grad_fast2(x));
-                    if (rows_left >= 32) {
-                        csum[j] += v[0] + v[1];
-                    } else {                     // last row tile of the matrix (uniform branch): rows >= M hold duplicates of row M-1
+                    csum[j] += v[0] + v[1];
+                    if (rows_left < 32) {        // last row tile of the matrix (uniform branch): rows >= M hold duplicates of row M-1
+                        // (subtracting what was just added keeps the hot path free of selects: masking BEFORE the add costs
+                        // the TM = 4 kernel 212 B of scratch and 75 us per launch)
                         const int row = 2 * ((k & 1) + 4 * (k >> 1) + 2 * h);
-                        csum[j] += (row < rows_left ? v[0] : 0.f) + (row + 1 < rows_left ? v[1] : 0.f);
+                        csum[j] -= (row < rows_left ? 0.f : v[0]) + (row + 1 < rows_left ? 0.f : v[1]);
                     }
                 }
                 pk[j][k] = cvt_pk_bf16(v[0], v[1]);

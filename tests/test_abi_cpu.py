@@ -182,3 +182,40 @@ def test_comm_entry_points_without_a_gpu():
         assert any(buf.raw)                                   # an ncclUniqueId was produced
     else:                                                     # a box without librccl: a clean error, not a crash
         assert rc == -4 and b"rccl" in lib.pa_comm_last_error().lower()
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    """A register spill inside a hot loop once cost 75 us per launch without failing any parity test: every kernel of the
+    default bf16 step must fit its registers (.private_segment_fixed_size == 0 in the code objects' metadata)."""
+    so = os.path.join(ROOT, "passt_amd", "libpasst_amd.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not os.path.exists(so) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or llvm tools not available")
+    objcopy, bundler, readelf = tools
+    names, sizes = [], []
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", so, os.path.join(d, "copy.so")], check=True, capture_output=True)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        assert starts, "no offload bundles in .hip_fatbin"
+        for k, st in enumerate(starts):                       # one bundle per translation unit
+            part, co = os.path.join(d, f"b{k}.bin"), os.path.join(d, f"b{k}.co")
+            open(part, "wb").write(blob[st:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            r = subprocess.run([bundler, "--type=o", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}",
+                                f"--output={co}"], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True).stdout
+            for blk in notes.split(".agpr_count")[1:]:       # one metadata map per kernel
+                n = re.search(r"\.name:\s+(\S+)", blk)
+                z = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+                if n and z:
+                    names.append(n.group(1))
+                    sizes.append(int(z.group(1)))
+    assert len(names) > 40, len(names)
+    # A/B-only tile variants and wide LayerNorm instantiations may spill; the kernels of the default bf16 step must not
+    spilled = [n for n, z in zip(names, sizes) if z > 0]
+    hot = [n for n in spilled if "gemm_tn_stagger" in n or ("DF16b" in n and ("gemm_nt_stagger_kernel" in n or "attn_" in n))]
+    assert not hot, hot
