@@ -344,8 +344,9 @@ def _pick_batched_splits(probs, slots=256):
     return best if best is not None else [1] * len(probs)
 
 
-def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
-    """out[N][K] (+)= dY[M][N]^T X[M][K], operands read in place (pa_gemm_tn), deterministic split-K."""
+def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None, db=None):
+    """out[N][K] (+)= dY[M][N]^T X[M][K], operands read in place (pa_gemm_tn), deterministic split-K.  db [N] f32 (bf16
+    role-split kernel only, see wgrad_tn_fuses_bias): (+)= column sums of dY out of the same launch."""
     Mtok, N = dY.shape
     K = X.shape[1]
     if dtype == PA_BF16 and GEMM_TUNE != 1:      # role-split 256x256 kernel, one workgroup per CU
@@ -355,10 +356,11 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         mrows = 64 if dtype == PA_BF16 else 32
         S = pick_split_k(tiles, (Mtok + mrows - 1) // mrows)
-    need = S * N * K
+    assert db is None or wgrad_tn_fuses_bias(dtype)
+    need = S * N * K + (S * N if db is not None else 0)
     if partial_ws is None or partial_ws.numel() < need:
         partial_ws = torch.empty(need, device=dY.device, dtype=torch.float32)
-    part = partial_ws[:need].view(S, N, K)
+    part = partial_ws[:S * N * K].view(S, N, K)
     a = GemmArgs()
     a.dtype, a.epilogue = dtype, EPI_PARTIAL
     a.M, a.N, a.K = N, K, Mtok
@@ -367,6 +369,8 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
     a.out_f32, a.ldo32 = _p(part), K
     a.split_k = S
     a.tune = GEMM_TUNE
+    bpart = partial_ws[S * N * K:need] if db is not None else None
+    a.colsum_ws = _p(bpart)
     lib = _lib.load()
     if GEMM_PROFILE is None:
         check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
@@ -377,7 +381,14 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None):
         ev1.record()
         GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, 2.0 * N * K * Mtok))
     check(lib.pa_reduce_partials(_p(part), S, N * K, _p(out_f32), int(accumulate), _stream()), "pa_reduce_partials")
+    if db is not None:
+        check(lib.pa_reduce_partials(_p(bpart), S, N, _p(db, torch.float32), int(accumulate), _stream()), "pa_reduce_partials")
     return partial_ws
+
+
+def wgrad_tn_fuses_bias(dtype):
+    """True when wgrad_tn / wgrad_tn_batched can return colsum(dY) from the weight-gradient launch itself."""
+    return dtype == PA_BF16 and GEMM_TUNE != 1
 
 
 def wgrad_tn_batched(problems, dtype, partial_ws=None):

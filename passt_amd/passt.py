@@ -301,8 +301,9 @@ def passt_forward(model, x, save):
 def _wgrad_pair(dY, X, dW, db, dt, scratch, accumulate):
     """dW[N][K] = dY^T X, db[N] = colsum(dY) from row-major dY[M][N], X[M][K], both read in place
     (pa_gemm_tn: transpose-read MFMA operands, deterministic split-K over tokens)."""
-    scratch["part"] = ops.wgrad_tn(dY, X, dW.view(dY.shape[1], -1), dt, accumulate, scratch.get("part"))
-    if db is not None:
+    fused = db is not None and ops.wgrad_tn_fuses_bias(dt) and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
+    scratch["part"] = ops.wgrad_tn(dY, X, dW.view(dY.shape[1], -1), dt, accumulate, scratch.get("part"), db=db if fused else None)
+    if db is not None and not fused:
         ops.colsum(dY, db, accumulate=accumulate)
 
 

@@ -628,5 +628,7 @@ def test_wgrad_tn_batched_matches_single_launches():
     for (dY, X, out, acc), ref in zip(probs, refs):
         assert rel_err(out, ref) < 3e-3
         single = torch.full_like(out, 0.5 if acc else 7.0)
-        ops.wgrad_tn(dY, X, single, dt, acc)
+        db1 = torch.full((dY.shape[1],), 0.5 if acc else 7.0, device=DEV)
+        ops.wgrad_tn(dY, X, single, dt, acc, db=db1)          # single launch, bias gradient from the same kernel
         assert rel_err(out, single.double().cpu()) < 1e-5     # same products, different split-K grouping
+        assert rel_err(db1, dY.double().cpu().sum(0) + (0.5 if acc else 0.0)) < 1e-5
