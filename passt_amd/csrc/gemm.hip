@@ -1377,13 +1377,13 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int ms, int cbase, 
 static constexpr int TN_ROWS = PA_TN_STEP_ROWS;          // tokens per stage (host code sizes the K slices in these units)
 #ifndef PA_TN_FRAG_PIPE
 // Three schedules of the same work were measured in the step, same box, same call (profiles/r02_tn_loop_variants.json):
-//   0: role split, fragment reads in the L segment                                   355.9 us per block launch
-//   1: role split, fragment reads issued inside the previous M segment               360.9
-//   2: lockstep, software pipelined, counted lgkmcnt waits, 2 barriers per stage     368.0
-// although the probe timeline (tools/probe_tn.py) shows variant 0 spending as long in L (~300-cycle loaded LDS latency)
-// as in M.  The kernel is at the chip's power budget: the same MFMA + LDS + fabric work costs the same energy in any
-// order, and saved cycles come back as lower clock (MI355X_MICROARCH.md, DVFS give-back).  Isolated on uniform random
-// data the launch takes 521 us, in the step on real gradients 356: the clock follows the data's toggle rate.
+//   0: role split, fragment reads in the L segment                                   355.9 us per block launch, 763 k cycles
+//   1: role split, fragment reads issued inside the previous M segment               360.9 us, 771 k
+//   2: lockstep, software pipelined, counted lgkmcnt waits, 2 barriers per stage     368.0 us, 801 k   (all at 2.03 GHz)
+// although the probe timeline (tools/probe_tn.py) shows variant 0 spending as long in L as in M.  What fills L is not the
+// twelve LDS reads (~300 cycles of loaded latency, hidden in 1 and 2) but the ISSUE of the LDS-DMA pieces (100-185 cycles
+// each inside a busy phase, MI355X_MICROARCH.md; two per wave and phase): the role split keeps it out of the instruction
+// stream of the wave that is issuing MFMAs, a lockstep loop puts it back in.
 #define PA_TN_FRAG_PIPE 0
 #endif
 #ifndef PA_TN_STAGES
