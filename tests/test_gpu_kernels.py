@@ -547,7 +547,8 @@ def test_persistent_gemm_edge_shapes(tune, M, N, K):
         ops.GEMM_TUNE = old
 
 
-@pytest.mark.parametrize("M,N,K", [(2304, 3072, 768), (1999, 3072, 768), (30336, 3072, 768), (777, 1024, 256), (4000, 4096, 1024)])
+@pytest.mark.parametrize("M,N,K", [(2304, 3072, 768), (1999, 3072, 768), (30336, 3072, 768), (777, 1024, 256), (4000, 4096, 1024),
+                                   (5003, 3072, 768), (8200, 1536, 768), (25280, 4096, 1024), (12345, 3136, 832)])
 def test_blocked_pre_activation_equals_row_major(M, N, K):
     """PA_GEMM_BLOCKED_PRE: fc1 + GELU writes the pre-activation in the blocked accumulator-order layout and the GELU'
     epilogue of the input-gradient GEMM reads it back: activation, d_pre and the fused fc1.bias column sums are
