@@ -1386,6 +1386,10 @@ static constexpr int TN_ROWS = PA_TN_STEP_ROWS;          // tokens per stage (ho
 // stream of the wave that is issuing MFMAs, a lockstep loop puts it back in.
 #define PA_TN_FRAG_PIPE 0
 #endif
+#ifndef PA_TN_LOCKSTEP_OFFSET
+#define PA_TN_LOCKSTEP_OFFSET 0   // variant 2 only: s_sleep units (64 cycles) group 1 waits after every stage barrier (A/B:
+                                  // 0 / 2 / 4 -> 359.8 / 371.6 / 376.6 us against 353.2 for the role split, run r10)
+#endif
 #ifndef PA_TN_STAGES
 #define PA_TN_STAGES 3         // (A/B: -DPA_TN_STEP_ROWS=64 -DPA_TN_STAGES=2 is the r01 pipeline)
 #endif
@@ -1607,6 +1611,9 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
             if (ph == NPH - 1) {           // B2: every wave is through with its reads of stage t's slot
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+#if PA_TN_LOCKSTEP_OFFSET
+                if (wr == 1) __builtin_amdgcn_s_sleep(PA_TN_LOCKSTEP_OFFSET);     // A/B: keep the two waves of a SIMD half a phase apart
+#endif
             }
             PA_PROBE_STAMP_TN(t >= 4 && t < 12, ((t - 4) * NPH + ph) * 4 + 3);
         };
