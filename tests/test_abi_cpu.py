@@ -219,3 +219,19 @@ def test_no_kernel_of_the_library_uses_scratch():
     spilled = [n for n, z in zip(names, sizes) if z > 0]
     hot = [n for n in spilled if "gemm_tn_stagger" in n or ("DF16b" in n and ("gemm_nt_stagger_kernel" in n or "attn_" in n))]
     assert not hot, hot
+
+
+def test_host_side_queries_answer_without_a_gpu():
+    """Pure host entry points of the C ABI (no device touched): the blocked pre-activation query / size and the token
+    step of the weight-gradient kernel that callers size their split-K slices with."""
+    from passt_amd import _lib
+    lib = _lib.load()
+    assert lib.pa_gemm_tn_step_rows() == 48
+    # headline MLP shape: role-split kernel -> blocked form available; rows padded to whole 256-row tiles
+    assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3072, 768) == 1
+    assert lib.pa_gemm_blocked_pre_elems(64 * 474, 3072) == 30464 * 3072
+    assert lib.pa_gemm_blocked_pre_elems(256, 64) == 256 * 64
+    # compact rows of the last block (2 per clip) run on the generic kernel; N must be a multiple of 64
+    assert lib.pa_gemm_blocked_pre_ok(128, 3072, 768) == 0
+    assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3080, 768) == 0
+    assert lib.pa_gemm_blocked_pre_ok(0, 3072, 768) == 0
