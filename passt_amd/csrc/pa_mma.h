@@ -44,6 +44,22 @@ __device__ __forceinline__ void mma32_first<float>(f32x16& acc, const f32x4& a, 
     for (int e = 1; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
 }
 
+// first product of a chain that starts from a given C operand: acc = a * b + c  (acc and c are different registers:
+// attention keeps a block of per-row offsets (-running max, -lse, -delta) and gets "score - offset" from the matrix
+// pipe instead of one VALU instruction per score)
+template <typename T>
+__device__ __forceinline__ void mma32_c(f32x16& acc, const typename Frag<T>::type& a, const typename Frag<T>::type& b, const f32x16& c);
+template <>
+__device__ __forceinline__ void mma32_c<bf16>(f32x16& acc, const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma32_c<float>(f32x16& acc, const f32x4& a, const f32x4& b, const f32x16& c) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 1; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+}
+
 // row of accumulator register r for this lane
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
