@@ -104,11 +104,11 @@ def main():
     add("colsum (bias grad) [M,3072] bf16", sec, bytes_=M * 4 * D * 2)
     # ---- attention ----
     qkv = rnd(M, 3 * D)
-    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125)
-    sec = timeit(lambda: ops.attention_fwd(qkv, B, H, N, 0.125), args.iters)
+    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED)
+    sec = timeit(lambda: ops.attention_fwd(qkv, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED), args.iters)
     add(f"attention fwd B{B} H{H} N{N}", sec, flops=4.0 * N * N * 64 * B * H)
     do = rnd(M, D)
-    sec = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, H, N, 0.125), args.iters)
+    sec = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED), args.iters)
     add(f"attention bwd (delta + dkdv + dq) B{B} H{H} N{N}", sec, flops=10.0 * N * N * 64 * B * H)
     # ---- layer norm ----
     g, b_ = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)

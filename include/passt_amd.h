@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale* */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -170,6 +170,10 @@ typedef struct {
     float* colsum_ws;
     int32_t colsum_accumulate;
     int32_t reserved;      /* flags: 0, or PA_GEMM_BLOCKED_PRE (bits 0..7 are ignored by the product library) */
+    /* PA_EPI_STORE only: out_lp[m][n] = (acc + bias[n]) * colscale for the columns n < colscale_n (a multiple of 64; 0 = off),
+     * one rounding.  The qkv Linear writes q * head_dim^-0.5 * log2(e) this way for pa_attention_*(PA_ATTN_Q_PRESCALED). */
+    int32_t colscale_n;
+    float colscale;
 } pa_gemm_args;
 /* PA_EPI_GELU: out_lp (the pre-activation) is written, PA_EPI_DGELU: aux (the same tensor) is read, in the library's
  * blocked layout instead of row-major -- 4 KiB blocks of 32 rows x 64 columns in MFMA accumulator order, which both
@@ -242,15 +246,23 @@ int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumul
  * nq (1..N): only the first nq queries of every sequence are produced -- N for a normal block; 2 for the LAST
  * block, whose output is only ever read at the cls/dist rows (models/passt.py:570-574).  o, d_o, lse and delta are
  * then COMPACT: o[(b*nq + q)][H*64], lse[(b*H + h)*nq + q].  K and V always span all N tokens.
+ *
+ * flags: 0, or PA_ATTN_Q_PRESCALED: the q third of qkv holds q * scale * log2(e) (the qkv GEMM wrote it so:
+ * pa_gemm_args.colscale_n / colscale, one rounding).  The kernels then take "score - row reference" straight from the
+ * matrix pipe (no multiply-add per score); o, lse and every gradient are the same quantities as without the flag
+ * (dqkv's q third is the gradient with respect to the UNSCALED q).  The same flag must be given to fwd and bwd.
  * ------------------------------------------------------------------------------------------ */
+#define PA_ATTN_Q_PRESCALED 1
 int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
-                     float scale, int dtype, void* stream);
-/* dqkv[B*N][3*H*64] from d_o[B*nq][H*64]; lse from the forward; delta: f32 workspace [2*B*H*nq] (per-query
- * scalars the dQ kernel hands to the dK/dV kernel: rowsum(dO*O)*scale, then -lse*log2 e).  The K and V thirds
+                     float scale, int dtype, int flags, void* stream);
+/* number of floats of pa_attention_bwd's `delta` workspace */
+int64_t pa_attention_bwd_ws_floats(int B, int H, int nq);
+/* dqkv[B*N][3*H*64] from d_o[B*nq][H*64]; lse from the forward; delta: f32 workspace of pa_attention_bwd_ws_floats()
+ * (per-query scalars the dQ kernel hands to the dK/dV kernel: -rowsum(dO*O), then -lse*log2 e).  The K and V thirds
  * of dqkv are written for all N tokens, the Q third only for rows q < nq (the caller zeroes the rest: pa_zero2d). */
 int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
                      const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
-                     float scale, int dtype, void* stream);
+                     float scale, int dtype, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch embedding + positional terms + Patchout: PatchEmbed.forward (models/passt.py:318-328) and

@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("ldr", i32), ("row_mod", i32), ("out_batch_rows", i32), ("out_row_off", i32),
                 ("aux", vp), ("ldaux", i32), ("out_f32", vp), ("ldo32", i32), ("out_lp", vp),
                 ("ldolp", i32), ("out_lp2", vp), ("ldolp2", i32), ("split_k", i32), ("tune", i32),
-                ("colsum_out", vp), ("colsum_ws", vp), ("colsum_accumulate", i32), ("reserved", i32)]
+                ("colsum_out", vp), ("colsum_ws", vp), ("colsum_accumulate", i32), ("reserved", i32),
+                ("colscale_n", i32), ("colscale", f32)]
 
 
 class ReduceDesc(C.Structure):         # == pa_reduce_desc
@@ -67,8 +68,9 @@ SIGNATURES = {
     "pa_reduce_partials": (i32, [vp, i32, i64, vp, i32, vp]),
     "pa_rowsum": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "pa_colsum_f32": (i32, [vp, i32, i32, i32, vp, i32, vp]),
-    "pa_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
-    "pa_attention_bwd": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "pa_attention_fwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "pa_attention_bwd_ws_floats": (i64, [i32, i32, i32]),
+    "pa_attention_bwd": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp]),
     "pa_gather_rows": (i32, [vp, vp, i32, i64, vp, vp]),
     "pa_scatter_rows": (i32, [vp, vp, i32, i64, vp, vp]),
     "pa_zero2d": (i32, [vp, i64, i64, i64, vp]),
@@ -115,7 +117,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype, fn.argtypes = res, args
-    if lib.pa_abi_version() != 1:
+    if lib.pa_abi_version() != 2:      # include/passt_amd.h PA_ABI_VERSION
         raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -28,35 +28,12 @@ namespace pa {
 #ifndef PA_ATTN_DKDV_WAVES
 #define PA_ATTN_DKDV_WAVES 2
 #endif
-// 1: forward row sums l from a fifth product against a fragment of ones (matrix pipe); 0: 32 VALU adds per tile
-#ifndef PA_ATTN_ONES
-#define PA_ATTN_ONES 1
-#endif
-// timing ablations of the forward kernel (WRONG RESULTS; tools/runs/*): bit 0 no running-max logic, 1 no exponentials,
-// 2 no P V product, 3 no Q K^T product, 4 no per-tile staging / barrier (tile 0 is reused)
-#ifndef PA_ATTN_ABLATE
-#define PA_ATTN_ABLATE 0
-#endif
-// Wave priorities.  The co-resident waves of a SIMD belong to different workgroups that start together and run the same
-// code: with equal priority the arbiter round-robins them, so they pass through the matrix phase (Q K^T, P V) and the
-// VALU phase (max, exp, convert) of a tile TOGETHER and the two pipes never overlap (r3 ablations: the phase times add
-// up).  1: static, distinct priority per hardware wave slot (HW_ID.wave_id & 3): the arbiter then serves the waves in
-// a fixed order, they drift apart by one phase and one wave's matrix phase runs under the others' VALU phases.
+// Wave priorities (A/B knob).  1: static, distinct priority per hardware wave slot (HW_ID.wave_id & 3), 2: per workgroup
+// id.  Tried in round 3 against the observation that the co-resident waves of a SIMD pass through the matrix phase and
+// the VALU phase of a tile together: no gain (fwd 71.4 -> 74.5 us, profiles/r03_attention_experiments.md), default off.
 #ifndef PA_ATTN_PRIO
 #define PA_ATTN_PRIO 0
 #endif
-// forward kernel: 1 = software-pipelined over key tiles (attn_fwd_pipe_kernel), 0 = plain loop
-#ifndef PA_ATTN_PIPE
-#define PA_ATTN_PIPE 1
-#endif
-#ifndef PA_ATTN_PIPE_WAVES
-#define PA_ATTN_PIPE_WAVES 2
-#endif
-// 1: sched_group_barrier interleave of part A (1 MFMA : 4 v_exp : 2 v_cvt_pk)
-#ifndef PA_ATTN_SGB
-#define PA_ATTN_SGB 1
-#endif
-
 static constexpr int HD = 64;       // head dim (all PaSST archs: 768/12, 1024/16, 384/6, 128/2)
 static constexpr int TROWS = 64;    // streamed rows per LDS tile
 static constexpr float LOG2E = 1.4426950408889634f;
@@ -138,38 +115,126 @@ __device__ __forceinline__ f32x4 col_frag<float>(const char* lds, int rbase, int
     return f;
 }
 
-// Wait until at most PENDING younger LDS operations are outstanding and tie the fragments to the wait, so no use
-// of them can be scheduled above it.  f32 fragments come from plain loads the compiler tracks itself: no-op.
-template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b) {
-    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PENDING));
-}
-template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b, F& c, F& d) {
-    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8))
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(PENDING));
-}
-
-// Transposed store of two 32x32 accumulator tiles acc[db] (lane = owned row, register = d) as rows of
-// 64 contiguous elements: through a per-wave [32][65] f32 LDS slab.
+// ---- lane-constant address parts, computed once per kernel (round 3) -------------------------------------------
+// The tile loops used to spend ~30 VALU instructions per 64-row tile on addresses (64-bit row pointers of the LDS-DMA
+// requests with their clamps, swizzled LDS offsets); with the matrix pipe and the VALU of a SIMD running one after the
+// other (tests/probes/probe_mfma_valu_overlap.hip) every one of them is kernel time.  What is left in the loops is one
+// uniform pointer per tensor and tile (SALU) and one v_add per LDS address register and tile.
+template <typename T> struct LaneOff {
+    static constexpr int PER_WAVE = Tile<T>::BYTES / 4096;      // LDS-DMA requests per wave and tile: 2 (bf16) / 4 (f32)
+    uint32_t rowf[Tile<T>::NFRAG];                              // LDS: row fragment st of tile row (lane & 31)
+    uint32_t colf[2][2];                                        // LDS (bf16): the two transposed 8-byte reads of column block db
+};
+// global byte offsets of this lane's 16-byte chunk in the wave's DMA requests for a tile whose rows 0..row_limit exist
+// (rows beyond are clamped to row_limit); ldb = row pitch in bytes
 template <typename T>
-__device__ __forceinline__ void store_rows_T(float* slab, const f32x16 (&acc)[2], float mul, T* gout,
-                                             int64_t ld, int row0, int nvalid_rows, int lane) {
+__device__ __forceinline__ void stage_offsets(uint32_t (&voff)[LaneOff<T>::PER_WAVE], int ldb, int row_limit, int wave, int lane) {
+    constexpr int RPI = 1024 / Tile<T>::RB;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int i = 0; i < LaneOff<T>::PER_WAVE; ++i) {
+        const int row = (wave * LaneOff<T>::PER_WAVE + i) * RPI + lane / Tile<T>::CPR;
+        const int pc = lane % Tile<T>::CPR;
+        const int c = Tile<T>::RB == 128 ? (pc ^ swz_f128(row)) : (pc ^ (row & 15));
+        voff[i] = (uint32_t)min(row, row_limit) * (uint32_t)ldb + (uint32_t)c * 16u;
+    }
+}
+// tile_base: uniform pointer to row 0 of the tile in global memory
+template <typename T>
+__device__ __forceinline__ void stage_tile_off(char* lds, const char* tile_base, const uint32_t (&voff)[LaneOff<T>::PER_WAVE], int wave) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(lane & 31) * 65 + db * 32 + acc_row(r, lane)] = acc[db][r] * mul;
-    // same-wave LDS RAW is ordered; mul may differ per lane (1/l), applied before the transpose.
-    // Rows leave as 16-byte vectors: lane -> row it*8 + lane/8, columns (lane&7)*8 .. +8
+    for (int i = 0; i < LaneOff<T>::PER_WAVE; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + voff[i]),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * LaneOff<T>::PER_WAVE + i) * 1024), 16, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void lane_offsets(LaneOff<T>& lo, int lane) {
+    const int row = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3), c0 = (lane & 7) * 8;
-        float v[8];
+    for (int st = 0; st < Tile<T>::NFRAG; ++st) lo.rowf[st] = (uint32_t)swz<Tile<T>::RB>(row, st * 2 + h);
+    if constexpr (sizeof(T) == 2) {
+        const int p = lane & 15, g = (lane >> 4) & 1;
+        const int r1 = 4 * h + (p >> 2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = slab[row * 65 + c0 + e];
-        if (row < nvalid_rows) store8<T>(gout + (int64_t)(row0 + row) * ld + c0, v);
+        for (int db = 0; db < 2; ++db) {
+            const int d = db * 32 + g * 16 + (p & 3) * 4;
+            lo.colf[db][0] = (uint32_t)(swz128(r1, d >> 3) + (d & 7) * 2);
+            lo.colf[db][1] = (uint32_t)(swz128(r1 + 8, d >> 3) + (d & 7) * 2);
+        }
+    }
+}
+// row fragment st of tile row rbase + (lane & 31), rbase a multiple of 32 (the swizzle does not see it): lds = tile base
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type row_frag_off(const char* lds, const LaneOff<T>& lo, int rbase, int st) {
+    return *(const typename Frag<T>::type*)(lds + rbase * Tile<T>::RB + lo.rowf[st]);
+}
+// column fragment (see col_frag) from the precomputed lane offsets; bf16: issued only, settle with col_settle<>()
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type col_frag_off(const char* lds, const LaneOff<T>& lo, int rbase, int s, int db, int lane) {
+    if constexpr (sizeof(T) == 2) {
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+        const int row_off = (rbase + 16 * s) * 128;
+        const bf16x4 lw = lds_tr16_asm_imm(base + lo.colf[db][0], row_off);
+        const bf16x4 hi = lds_tr16_asm_imm(base + lo.colf[db][1], row_off);
+        bf16x8 f;
+        f[0] = lw[0]; f[1] = lw[1]; f[2] = lw[2]; f[3] = lw[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    } else {
+        return col_frag<T>(lds, rbase, s, db * 32, lane);
     }
 }
 
-static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
+// Wait until at most PENDING younger LDS operations are outstanding and tie the fragments to the wait, so no use
+// of them can be scheduled above it.  f32 fragments come from plain loads the compiler tracks itself: no-op.
+#ifndef PA_ATTN_DEBUG_WAIT
+#define PA_ATTN_DEBUG_WAIT 0
+#endif
+
+template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b) {
+    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8)) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PA_ATTN_DEBUG_WAIT ? 0 : PENDING));
+}
+template <int PENDING, typename F> __device__ __forceinline__ void col_settle(F& a, F& b, F& c, F& d) {
+    if constexpr (sizeof(F) == 16 && __is_same(F, bf16x8))
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(PA_ATTN_DEBUG_WAIT ? 0 : PENDING));
+}
+
+// Store two 32x32 accumulator tiles acc[db] (lane = owned row, register = d) as rows of 64 contiguous elements
+// straight from the registers: the lanes (q, h = 0 / 1) of a row hold alternating groups of 4
+// consecutive columns, 8g + 4h + {0..3}.  f32: one 16-byte store per group.  bf16: a group is 8 bytes; the two lanes of a
+// row trade the odd / even groups with v_permlane32_swap (guide T21) and store 16 bytes each.
+template <typename T>
+__device__ __forceinline__ void store_rows_direct(const f32x16 (&acc)[2], float mul, T* gout, int64_t ld, int row0,
+                                                  int nvalid_rows, int lane) {
+    const int q = lane & 31, h = lane >> 5;
+    T* rowp = gout + (int64_t)(row0 + q) * ld;
+    const bool ok = q < nvalid_rows;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul};
+                if (ok) *(f32x4*)(rowp + db * 32 + 8 * g + 4 * h) = v;
+            }
+        } else {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t w[4];                                   // groups 2gp (w[0..1]) and 2gp + 1 (w[2..3]) as packed bf16 pairs
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x2 pk = {(bf16)(acc[db][8 * gp + 2 * i] * mul), (bf16)(acc[db][8 * gp + 2 * i + 1] * mul)};
+                    w[i] = __builtin_bit_cast(uint32_t, pk);
+                }
+                // lower half keeps its group 2gp and receives the upper half's; upper half keeps 2gp+1 and receives the lower's
+                const auto r0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *(u32x4*)(rowp + db * 32 + 16 * gp + 8 * h) = v;
+            }
+        }
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Instruction budget (round 3).  At head dim 64 a 32-query x 64-key tile is only 16 MFMAs (512 matrix-pipe cycles per
@@ -190,26 +255,10 @@ static constexpr int SLAB_BYTES = 4 * 32 * 65 * 4;   // 33280
 // ------------------------------------------------------------------------------------------------
 static constexpr float RESCALE_LOG2 = 6.0f;
 
-// ---- probe builds only (-DPA_ATTN_PROBE, tools/probe_attn.py): s_memtime at the phase boundaries of the plain forward
-// loop, summed over all waves and tiles into g_attn_probe[phase] (cycles) and g_attn_probe[8] (tiles)
-#ifdef PA_ATTN_PROBE
-static constexpr int PROBE_WAVES = 16384;
-__device__ unsigned long long g_attn_probe[PROBE_WAVES * 8];   // per wave: 5 phase sums, tiles, first and last stamp
-#define PA_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PA_STAMP(var) do {} while (0)
-#endif
-
 template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_splat(float v) {
     typename Frag<T>::type f;
 #pragma unroll
     for (int e = 0; e < Tile<T>::EPC; ++e) f[e] = (T)v;
-    return f;
-}
-template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_scale(const typename Frag<T>::type& a, float c) {
-    typename Frag<T>::type f;
-#pragma unroll
-    for (int e = 0; e < Tile<T>::EPC; ++e) f[e] = (T)((float)a[e] * c);
     return f;
 }
 __device__ __forceinline__ f32x16 acc_splat(float v) {
@@ -254,27 +303,38 @@ __device__ __forceinline__ float other_half(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// Workgroup -> (block of 128 queries / keys, sequence x head).  The blocks of one head read the same K / V (resp. Q /
+// Work item -> (block of 128 queries / keys, sequence x head).  The blocks of one head read the same K / V (resp. Q /
 // dO) panels, 121 KB per head: they only share them through an L2 if they run on the same XCD, and the dispatcher
-// deals consecutive workgroup ids round-robin over the 8 XCDs.  So the grid is one-dimensional and id L is read as
-// XCD x = L & 7, slot s = L >> 3: head = x + 8 * (s / nblk), block = s % nblk -- the nblk blocks of a head are
-// consecutive slots of ONE XCD.  (With the (block, head) grid they sat on nblk different XCDs and every block
-// re-fetched the panels over the fabric: FETCH_SIZE 393 MB per forward launch for 187 MB of operands,
-// profiles/r02_pmc_fetch_run_r04.txt.)
-__device__ __forceinline__ bool attn_block(int nblk, int BH, int& blk, int& bh) {
-    const int L = blockIdx.x, s = L >> 3;
+// deals consecutive workgroup ids round-robin over the 8 XCDs.  So item id L is read as XCD x = L & 7, slot s = L >> 3:
+// head = x + 8 * (s / nblk), block = s % nblk -- the nblk blocks of a head are consecutive slots of ONE XCD.  (With a
+// (block, head) grid they sat on nblk different XCDs and every block re-fetched the panels over the fabric: FETCH_SIZE
+// 393 MB per forward launch for 187 MB of operands, profiles/r02_pmc_fetch_run_r04.txt.)
+__device__ __forceinline__ bool attn_item(int L, int nblk, int BH, int& blk, int& bh) {
+    const int s = L >> 3;
     const int g = s / nblk;
     blk = s - g * nblk;
     bh = (L & 7) + 8 * g;
     return bh < BH;
 }
+__device__ __forceinline__ bool attn_block(int nblk, int BH, int& blk, int& bh) { return attn_item(blockIdx.x, nblk, BH, blk, bh); }
 static inline unsigned attn_grid(int nblk, int BH) { return (unsigned)(nblk * 8 * ((BH + 7) / 8)); }
 
-template <typename T>
+// Round 3 (profiles/r03_attention_experiments.md).  The matrix pipe and the VALU of a SIMD do not overlap across waves
+// (tests/probes/probe_mfma_valu_overlap.hip: 8 MFMAs + 40 FMAs from two waves take 199 ns against 158 + 56 alone), and
+// the kernel's own counters say the same (matrix-busy 0.39 + VALU-busy 0.54 of the time): its time is the SUM of the
+// two instruction streams, so every VALU instruction per tile is ~1 ns per wave-tile.  Variants that re-arranged the
+// same instructions all measured slower than this plain loop at 3 waves per SIMD: software-pipelined over two key tiles
+// (2 waves), persistent with the next item's operands requested ahead, one 32-key block at a time (4 waves, spills),
+// static per-slot wave priorities.  So this loop is about instruction COUNT: scores leave the MFMA as "score - reference"
+// (C operand), lazy reference moves, row sums as plain adds (a fifth product against ones costs 4 MFMAs = 76 ns per tile,
+// 32 adds cost 32), tail masks only in the tail instance, addresses precomputed per lane (LaneOff), rows stored straight
+// from the registers, and waves without a query row skip the arithmetic.
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_FWD_WAVES : 2))) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
                                                        int ldo, float* __restrict__ lse, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using F = typename Frag<T>::type;
+    constexpr int NF = Tile<T>::NFRAG, NSB = AccSteps<T>::N, TB = Tile<T>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk, bh;
@@ -285,48 +345,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;      // q of token 0 of this (b,h)
     const int q0 = blk * 128 + wave * 32;
     const int qrow = min(q0 + (lane & 31), N - 1);
+    const bool active = q0 < nq;                                // wave-uniform: this wave owns at least one stored query
     const float sl2 = scale * LOG2E;
+    const int ldb = ldqkv * (int)sizeof(T);
 
-    F qf[Tile<T>::NFRAG];                                       // Q * scale * log2(e): scores arrive in log2 units
+    F qf[NF];                                                   // PRE: Q * scale * log2(e), scores arrive in log2 units
 #pragma unroll
-    for (int s = 0; s < Tile<T>::NFRAG; ++s)
-        qf[s] = frag_scale<T>(*(const F*)(base + (int64_t)qrow * ldqkv + (s * 2 + (lane >> 5)) * Tile<T>::EPC), sl2);
-    const F ones = frag_splat<T>(1.0f);
+    for (int s = 0; s < NF; ++s) qf[s] = *(const F*)(base + (int64_t)qrow * ldqkv + (s * 2 + (lane >> 5)) * Tile<T>::EPC);
+    LaneOff<T> lo;
+    lane_offsets<T>(lo, lane);
+    uint32_t voff[LaneOff<T>::PER_WAVE];
+    stage_offsets<T>(voff, ldb, TROWS, wave, lane);             // full tiles: no clamp
 
     f32x16 oacc[2] = {acc_splat(0.f), acc_splat(0.f)};
-    f32x16 lacc = acc_splat(0.f);                               // every register: l of this lane's query
-    float l_valu = 0.f;                                         // PA_ATTN_ONES == 0: l from VALU adds
     f32x16 negm = acc_splat(0.f);                               // C operand of the score chains: -m_run
-    float m_run = 0.f;                                          // reference point of the exponentials, log2 units
+    float m_run = 0.f, l_run = 0.f;                             // reference point (log2 units); this lane's HALF of the row sum
 
     const int ntiles = (N + TROWS - 1) / TROWS;
     // double-buffered K/V tiles: stage kt+1 by LDS-DMA while computing kt; one barrier per tile
-    auto stage = [&](int buf, int kt) {
-        char* sb = smem + buf * (2 * Tile<T>::BYTES);
-        stage_tile<T>(sb, base + D, ldqkv, kt * TROWS, N, wave, lane);
-        stage_tile<T>(sb + Tile<T>::BYTES, base + 2 * D, ldqkv, kt * TROWS, N, wave, lane);
+    const char* gK = (const char*)(base + D);
+    const char* gV = (const char*)(base + 2 * D);
+    auto stage = [&](int buf, int kt, const uint32_t (&vo)[LaneOff<T>::PER_WAVE]) {
+        char* sb = smem + buf * (2 * TB);
+        const int64_t row0 = (int64_t)kt * TROWS * ldb;
+        stage_tile_off<T>(sb, gK + row0, vo, wave);
+        stage_tile_off<T>(sb + TB, gV + row0, vo, wave);
     };
-    // one key tile; LAST = the tile that may hold keys >= N (masks, skipped half)
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)pt; (void)ps;
-    auto tile = [&](auto last_tag, int kt) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        PA_STAMP(pt[1]);
-        const char* sK = smem + (kt & 1) * (2 * Tile<T>::BYTES);
-        const char* sV = sK + Tile<T>::BYTES;
-        const bool both = !LAST || kt * TROWS + 32 < N;         // wave-uniform: the second 32 keys exist
+    // one key tile; LAST = the tile that may hold keys >= N (masks), BOTH = its second 32 keys exist.  Both are compile
+    // time: the P V loop below must be straight-line code.  Its column fragments come from asm LDS reads the compiler does
+    // not track; with a run-time step count it merged the paths with register copies of fragments whose data was still in
+    // flight (placed in front of the counted wait) -- sporadic garbage rows at B = 64, tools/check_lds_asm.py lints for it.
+    auto tile = [&](auto last_tag, auto both_tag, int kt) {
+        constexpr bool LAST = decltype(last_tag)::value, both = decltype(both_tag)::value;
+        const char* sK = smem + (kt & 1) * (2 * TB);
+        const char* sV = sK + TB;
         f32x16 s[2];
         // S'^T[key][q] = K (Q sl2)^T - m_run
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && !both) break;
-            if (PA_ATTN_ABLATE & 8) { s[kb] = negm; asm volatile("" : "+v"(s[kb])); continue; }
-            mma32_c<T>(s[kb], row_frag<T>(sK, kb * 32 + (lane & 31), 0, lane), qf[0], negm);
+            if constexpr (PRE) mma32_c<T>(s[kb], row_frag_off<T>(sK, lo, kb * 32, 0), qf[0], negm);
+            else mma32_first<T>(s[kb], row_frag_off<T>(sK, lo, kb * 32, 0), qf[0]);
 #pragma unroll
-            for (int st = 1; st < Tile<T>::NFRAG; ++st)
-                mma32<T>(s[kb], row_frag<T>(sK, kb * 32 + (lane & 31), st, lane), qf[st]);
+            for (int st = 1; st < NF; ++st) mma32<T>(s[kb], row_frag_off<T>(sK, lo, kb * 32, st), qf[st]);
+            if constexpr (!PRE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = fmaf(s[kb][r], sl2, -m_run);
+            }
         }
-        PA_STAMP(pt[2]);
         if (LAST && (N & (TROWS - 1))) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -345,8 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         }
         mx = fmaxf(mx, other_half(mx));
-        PA_STAMP(pt[3]);
-        if (!(PA_ATTN_ABLATE & 1) && (kt == 0 || !__all(mx <= RESCALE_LOG2))) {
+        if (kt == 0 || !__all(mx <= RESCALE_LOG2)) {
             // move the reference point: exactly to the row max on the first tile, up to it later
             const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll
@@ -356,250 +421,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 for (int r = 0; r < 16; ++r) s[kb][r] -= d;
             }
             m_run += d;
-            negm = acc_splat(-m_run);
+            if constexpr (PRE) negm = acc_splat(-m_run);
             if (kt != 0) {
                 const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-                if (PA_ATTN_ONES) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-                } else {
-                    l_valu *= alpha;
-                }
+                l_run *= alpha;
             }
         }
+        float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && !both) break;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = (PA_ATTN_ABLATE & 2) ? s[kb][r] : __builtin_amdgcn_exp2f(s[kb][r]);
-        }
-        PA_STAMP(pt[4]);
-        if (!PA_ATTN_ONES) {
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && !both) break;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) psum += s[kb][r];
-            }
-            l_valu += psum + other_half(psum);
-        }
-        // O^T[d][q] += V^T[d][key] P^T[key][q], l[q] += 1^T P^T; the V column fragments of step i+1 are in flight
-        // under the MFMAs of step i
-        if (PA_ATTN_ABLATE & 4) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[0][r] += s[0][r]; if (both) oacc[1][r] += s[1][r]; }
-        } else {
-            constexpr int NSB = AccSteps<T>::N;
-            const int ns = both ? 2 * NSB : NSB;
-            F vfr[2][2];
-            auto issue = [&](int slot, int step) {
-                const int kb = step / NSB, st = step % NSB;
-#pragma unroll
-                for (int db = 0; db < 2; ++db) vfr[slot][db] = col_frag<T>(sV, kb * 32, st, db * 32, lane);
-            };
-            issue(0, 0);
-#pragma unroll
-            for (int step = 0; step < 2 * NSB; ++step) {
-                if (step >= ns) break;
-                const int kb = step / NSB, st = step % NSB;
-                if (step + 1 < ns) {
-                    issue((step + 1) & 1, step + 1);
-                    col_settle<4>(vfr[step & 1][0], vfr[step & 1][1]);
-                } else {
-                    col_settle<0>(vfr[step & 1][0], vfr[step & 1][1]);
-                }
-                const F pf = acc_frag<T>(s[kb], st);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) mma32<T>(oacc[db], vfr[step & 1][db], pf);
-                if (PA_ATTN_ONES) mma32<T>(lacc, ones, pf);
+            for (int r = 0; r < 16; ++r) {
+                s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+                psum += s[kb][r];
             }
         }
-        PA_STAMP(pt[5]);
-#ifdef PA_ATTN_PROBE
-        ps[0] += pt[1] - pt[0]; ps[1] += pt[2] - pt[1]; ps[2] += pt[3] - pt[2]; ps[3] += pt[4] - pt[3]; ps[4] += pt[5] - pt[4]; ps[5] += 1;
-#endif
-    };
-    PA_STAMP(pt[6]);
-    stage(0, 0);
-    for (int kt = 0; kt < ntiles - 1; ++kt) {
-        PA_STAMP(pt[0]);
-        if (!(PA_ATTN_ABLATE & 16) || kt == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (!(PA_ATTN_ABLATE & 16)) stage((kt + 1) & 1, kt + 1);
-        }
-        tile(std::false_type{}, (PA_ATTN_ABLATE & 16) ? 0 : kt);
-    }
-    PA_STAMP(pt[0]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    tile(std::true_type{}, (PA_ATTN_ABLATE & 16) ? 0 : ntiles - 1);
-#ifdef PA_ATTN_PROBE
-    if (lane == 0 && blockIdx.x * 4 + wave < PROBE_WAVES) {
-        for (int i = 0; i < 5; ++i) g_attn_probe[(blockIdx.x * 4 + wave) * 8 + i] = ps[i];
-        g_attn_probe[(blockIdx.x * 4 + wave) * 8 + 5] = ps[5] | ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8) |
-                                                        ((unsigned long long)__builtin_amdgcn_s_getreg(20 /*XCC_ID*/ | (0 << 6) | (3 << 11)) << 40);
-        g_attn_probe[(blockIdx.x * 4 + wave) * 8 + 6] = pt[6];
-        g_attn_probe[(blockIdx.x * 4 + wave) * 8 + 7] = pt[5];
-    }
-#endif
-    __syncthreads();   // tiles are dead; reuse LDS for the transposed store
-    // only the first nq queries of every sequence are produced; o / lse are compact (nq rows per sequence)
-    if (q0 < nq) {
-        const float l_run = PA_ATTN_ONES ? lacc[0] : l_valu;
-        if (lane < 32 && q0 + lane < nq) lse[(int64_t)bh * nq + q0 + lane] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;   // natural log units
-        store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, __builtin_amdgcn_rcpf(l_run), o + (int64_t)b * nq * ldo + h * HD,
-                        ldo, q0, min(32, nq - q0), lane);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward, software-pipelined over key tiles (PA_ATTN_PIPE).  The plain loop above runs a tile as three dependent
-// phases -- Q K^T (matrix pipe), max / exp / convert (VALU), P V (matrix pipe) -- and the waves that share a SIMD start
-// together and run the same code, so they sit in the same phase at the same time: the r3 ablation builds show the phase
-// times adding up (matrix-pipe busy 0.39 + VALU busy 0.54 of the kernel time) instead of overlapping.  Here every wave
-// carries two tiles: iteration j issues
-//   part A:  S'(j+1) = K(j+1) Q^T - m   (8 MFMAs)   beside   P(j) = exp2(S'(j)), bf16 fragments   (32 v_exp + 16 v_cvt_pk)
-//   part B:  O += V(j) P(j), l += 1 P(j)  (12 MFMAs) beside  row max of S'(j+1) and the (rare) reference move
-// so both pipes have independent work in flight at every point of a single wave's instruction stream.
-// LDS: K(t) and V(t) live in slot t & 1; iteration j needs K(j+1) and V(j), and its opening barrier frees the slots of
-// K(j) (re-filled with K(j+2)) and V(j-1) (re-filled with V(j+1)): one barrier per tile, every DMA has a full iteration to land.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_PIPE_WAVES : 1))) void attn_fwd_pipe_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ o,
-                                                       int ldo, float* __restrict__ lse, int H, int N, int nq, float scale, int nblk, int BH) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using F = typename Frag<T>::type;
-    constexpr int NF = Tile<T>::NFRAG, NSB = AccSteps<T>::N;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int blk, bh;
-    if (!attn_block(nblk, BH, blk, bh)) return;
-    wave_static_prio();
-    const int b = bh / H, h = bh % H;
-    const int D = H * HD;
-    const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;      // q of token 0 of this (b,h)
-    const int q0 = blk * 128 + wave * 32;
-    const int qrow = min(q0 + (lane & 31), N - 1);
-    const float sl2 = scale * LOG2E;
-
-    F qf[NF];                                                   // Q * scale * log2(e): scores arrive in log2 units
-#pragma unroll
-    for (int s = 0; s < NF; ++s)
-        qf[s] = frag_scale<T>(*(const F*)(base + (int64_t)qrow * ldqkv + (s * 2 + (lane >> 5)) * Tile<T>::EPC), sl2);
-    const F ones = frag_splat<T>(1.0f);
-
-    f32x16 oacc[2] = {acc_splat(0.f), acc_splat(0.f)};
-    f32x16 lacc = acc_splat(0.f);                               // every register: l of this lane's query
-    f32x16 negm = acc_splat(0.f);                               // C operand of the score chains: -m_run
-    float m_run = 0.f;                                          // reference point of the exponentials, log2 units
-    f32x16 s[2];                                                // S'(j), then P(j)
-
-    const int ntiles = (N + TROWS - 1) / TROWS;
-    auto slotK = [&](int t) { return smem + (t & 1) * (2 * Tile<T>::BYTES); };
-    auto slotV = [&](int t) { return smem + (t & 1) * (2 * Tile<T>::BYTES) + Tile<T>::BYTES; };
-    auto stageK = [&](int t) { stage_tile<T>(slotK(t), base + D, ldqkv, t * TROWS, N, wave, lane); };
-    auto stageV = [&](int t) { stage_tile<T>(slotV(t), base + 2 * D, ldqkv, t * TROWS, N, wave, lane); };
-
-    // scores of tile t into sn (C operand = -m_run); the second key block only if it holds a key < N
-    auto scores = [&](f32x16 (&sn)[2], int t, bool both) {
-        const char* sK = slotK(t);
-#pragma unroll
-        for (int st = 0; st < NF; ++st)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && !both) continue;
-                const F kf = row_frag<T>(sK, kb * 32 + (lane & 31), st, lane);
-                if (st == 0) mma32_c<T>(sn[kb], kf, qf[0], negm);
-                else mma32<T>(sn[kb], kf, qf[st]);
-            }
-    };
-    // the same for a full bf16 tile with all eight K fragments requested up front (asm reads: the compiler waits for
-    // every ds_read right in front of its MFMA, one LDS round trip per product); the waits are counted per product
-    auto scores_issue = [&](F (&kfr)[2 * NF], int t) {
-        const char* sK = slotK(t);
-#pragma unroll
-        for (int st = 0; st < NF; ++st)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                kfr[st * 2 + kb] = lds_b128_asm<F>(sK + swz<Tile<T>::RB>(kb * 32 + (lane & 31), st * 2 + (lane >> 5)));
-    };
-    auto scores_mma = [&](f32x16 (&sn)[2], F (&kfr)[2 * NF]) {
-#pragma unroll
-        for (int st = 0; st < NF; ++st) {
-            frag_settle(kfr[st * 2], kfr[st * 2 + 1], 2 * NF - 2 - 2 * st);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (st == 0) mma32_c<T>(sn[kb], kfr[kb], qf[0], negm);
-                else mma32<T>(sn[kb], kfr[st * 2 + kb], qf[st]);
-            }
-        }
-    };
-    // keys >= N of the last tile: -inf (one v_cndmask per score: the condition is uniform per half-wave and register)
-    auto mask_tail = [&](f32x16 (&sn)[2], int t, bool both) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kb == 1 && !both) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (t * TROWS + kb * 32 + acc_row(r, lane) >= N) sn[kb][r] = -INFINITY;
-        }
-    };
-    auto row_max = [&](const f32x16 (&sn)[2], bool both) {
-        float mx = sn[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sn[0][r]);
-        if (both) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sn[1][r]);
-        }
-        return fmaxf(mx, other_half(mx));
-    };
-    // move the reference point by d: scores of the coming tile, the C block and, except before the first tile, O and l
-    auto rebase = [&](f32x16 (&sn)[2], float d, bool both, bool scale_acc) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kb == 1 && !both) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sn[kb][r] -= d;
-        }
-        m_run += d;
-        negm = acc_splat(-m_run);
-        if (scale_acc) {
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; lacc[r] *= alpha; }
-        }
-    };
-
-    // ---- prologue: K(0), V(0), K(1) -> LDS; S'(0) and its exact row max
-    stageK(0);
-    stageV(0);
-    if (ntiles > 1) stageK(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bool both = TROWS / 2 < N;                                  // of the CURRENT tile (wave-uniform)
-    scores(s, 0, both);
-    if (ntiles == 1 && (N & (TROWS - 1))) mask_tail(s, 0, both);
-    rebase(s, row_max(s, both), both, false);
-
-    // HAS_NEXT: tile j+1 exists; NEXT_LAST: it is the last one (tail mask, maybe only one key block)
-    // P V of tile j (fragments pf) and, beside it, the row max of the coming tile's scores
-    auto pv_steps = [&](const F (&pf)[2][NSB], int j, bool bothc, F (&vfr)[2][2], bool first_issued) {
-        const char* sV = slotV(j);
-        const int ns = bothc ? 2 * NSB : NSB;
+        l_run += psum;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]; the V column fragments of step i+1 are in flight under the MFMAs of step i
+        constexpr int ns = both ? 2 * NSB : NSB;
+        F vfr[2][2];
         auto issue = [&](int slot, int step) {
             const int kb = step / NSB, st = step % NSB;
 #pragma unroll
-            for (int db = 0; db < 2; ++db) vfr[slot][db] = col_frag<T>(sV, kb * 32, st, db * 32, lane);
+            for (int db = 0; db < 2; ++db) vfr[slot][db] = col_frag_off<T>(sV, lo, kb * 32, st, db, lane);
         };
-        if (!first_issued) issue(0, 0);
+        issue(0, 0);
 #pragma unroll
-        for (int step = 0; step < 2 * NSB; ++step) {
-            if (step >= ns) break;
+        for (int step = 0; step < ns; ++step) {
             const int kb = step / NSB, st = step % NSB;
             if (step + 1 < ns) {
                 issue((step + 1) & 1, step + 1);
@@ -607,117 +458,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             } else {
                 col_settle<0>(vfr[step & 1][0], vfr[step & 1][1]);
             }
+            const F pf = acc_frag<T>(s[kb], st);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) mma32<T>(oacc[db], vfr[step & 1][db], pf[kb][st]);
-            mma32<T>(lacc, ones, pf[kb][st]);
+            for (int db = 0; db < 2; ++db) mma32<T>(oacc[db], vfr[step & 1][db], pf);
         }
     };
-    auto exp_block = [&](int kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+    // the last tile's rows are clamped to the last key (requested once; the only tile if N <= 64)
+    auto stage_last = [&](int buf) {
+        uint32_t vt[LaneOff<T>::PER_WAVE];
+        stage_offsets<T>(vt, ldb, N - 1 - (ntiles - 1) * TROWS, wave, lane);
+        stage(buf, ntiles - 1, vt);
     };
-    auto next_tile_max = [&](f32x16 (&sn)[2], int j, bool bothn, bool next_last) {
-        if (next_last && (N & (TROWS - 1))) mask_tail(sn, j + 1, bothn);
-        const float mx = row_max(sn, bothn);
-        if (!__all(mx <= RESCALE_LOG2)) rebase(sn, fmaxf(mx, 0.f), bothn, true);
-        s[0] = sn[0];
-        if (bothn) s[1] = sn[1];
-        both = bothn;
-    };
-    // hot iteration (bf16): tiles j and j+1 are full.  Order inside the wave: barrier, DMA requests, ALL LDS requests of
-    // part A, then the first sixteen exponentials while those are in flight, the eight score MFMAs with the other
-    // sixteen exponentials between them, then part B.
-    auto iter_hot = [&](int j) {
+    if (ntiles == 1) stage_last(0);
+    else stage(0, 0, voff);
+    for (int kt = 0; kt < ntiles - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (j + 2 < ntiles) stageK(j + 2);
-        stageV(j + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        F kfr[2 * NF], vfr[2][2];
-        scores_issue(kfr, j + 1);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) vfr[0][db] = col_frag<T>(slotV(j), 0, 0, db * 32, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        F pf[2][NSB];
-        exp_block(0);
-#pragma unroll
-        for (int st = 0; st < NSB; ++st) pf[0][st] = acc_frag<T>(s[0], st);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 sn[2];
-        // the V requests of step 0 are younger than the K requests: lgkmcnt counts them too
-#pragma unroll
-        for (int st = 0; st < NF; ++st) {
-            frag_settle(kfr[st * 2], kfr[st * 2 + 1], 2 * NF - 2 - 2 * st + 4);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (st == 0) mma32_c<T>(sn[kb], kfr[kb], qf[0], negm);
-                else mma32<T>(sn[kb], kfr[st * 2 + kb], qf[st]);
-            }
-        }
-        exp_block(1);
-#pragma unroll
-        for (int st = 0; st < NSB; ++st) pf[1][st] = acc_frag<T>(s[1], st);
-#if PA_ATTN_SGB
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);      // 2 transcendental
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // 1 VALU (convert)
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        pv_steps(pf, j, true, vfr, true);
-        next_tile_max(sn, j, true, false);
-    };
-    // HAS_NEXT: tile j+1 exists; NEXT_LAST: it is the last one (tail mask, maybe only one key block)
-    auto iter = [&](auto has_next_tag, auto next_last_tag, int j) {
-        constexpr bool HAS_NEXT = decltype(has_next_tag)::value, NEXT_LAST = decltype(next_last_tag)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (j + 2 < ntiles) stageK(j + 2);
-        if (HAS_NEXT) stageV(j + 1);
-        const bool bothn = !NEXT_LAST || (j + 1) * TROWS + 32 < N;
-        f32x16 sn[2];
-        if (HAS_NEXT) scores(sn, j + 1, bothn);
-        exp_block(0);
-        if (both) exp_block(1);
-        F pf[2][NSB], vfr[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < NSB; ++st)
-                if (kb == 0 || both) pf[kb][st] = acc_frag<T>(s[kb], st);
-        __builtin_amdgcn_sched_barrier(0);
-        pv_steps(pf, j, both, vfr, false);
-        if (HAS_NEXT) next_tile_max(sn, j, bothn, NEXT_LAST);
-    };
-    for (int j = 0; j < ntiles - 2; ++j) {
-        if constexpr (sizeof(T) == 2) iter_hot(j);
-        else iter(std::true_type{}, std::false_type{}, j);
+        if (kt + 2 < ntiles) stage((kt + 1) & 1, kt + 1, voff);
+        else stage_last((kt + 1) & 1);
+        if (active) tile(std::false_type{}, std::true_type{}, kt);
     }
-    if (ntiles > 1) iter(std::true_type{}, std::true_type{}, ntiles - 2);
-    iter(std::false_type{}, std::false_type{}, ntiles - 1);
-
-    __syncthreads();   // tiles are dead; reuse LDS for the transposed store
-    // only the first nq queries of every sequence are produced; o / lse are compact (nq rows per sequence)
-    if (q0 < nq) {
-        const float l_run = lacc[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) {
+        if ((ntiles - 1) * TROWS + 32 < N) tile(std::true_type{}, std::true_type{}, ntiles - 1);
+        else tile(std::true_type{}, std::false_type{}, ntiles - 1);
+        // only the first nq queries of every sequence are produced; o / lse are compact (nq rows per sequence)
+        l_run += other_half(l_run);
         if (lane < 32 && q0 + lane < nq) lse[(int64_t)bh * nq + q0 + lane] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;   // natural log units
-        store_rows_T<T>((float*)smem + wave * (32 * 65), oacc, __builtin_amdgcn_rcpf(l_run), o + (int64_t)b * nq * ldo + h * HD,
-                        ldo, q0, min(32, nq - q0), lane);
+        store_rows_direct<T>(oacc, __builtin_amdgcn_rcpf(l_run), o + (int64_t)b * nq * ldo + h * HD, ldo, q0, min(32, nq - q0), lane);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, part 1: dK, dV.  Workgroup owns 128 keys (lane = key); queries stream through LDS.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DKDV_WAVES : 1))) void attn_bwd_dkdv_kernel(const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ d_o, int ldo,
                                                             const float* __restrict__ ws, int64_t plane,
                                                             T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using F = typename Frag<T>::type;
+    constexpr int NF = Tile<T>::NFRAG, NS = AccSteps<T>::N, TB = Tile<T>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk, bh;
@@ -728,51 +511,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;
     const T* dobase = d_o + (int64_t)b * nq * ldo + h * HD;     // d_o / lse / delta: nq rows per sequence
     const int k0 = blk * 128 + wave * 32;
-    const int key = k0 + (lane & 31);
-    const int krow = min(key, N - 1);
+    const int krow = min(k0 + (lane & 31), N - 1);
     const bool active = k0 < N;                                 // wave-uniform
     const float sl2 = scale * LOG2E;
+    const int ldbq = ldqkv * (int)sizeof(T), ldbo = ldo * (int)sizeof(T);
 
-    F kf[Tile<T>::NFRAG], vf[Tile<T>::NFRAG];                   // kf = K * scale * log2(e) (used for the scores only)
+    F kf[NF], vf[NF];
 #pragma unroll
-    for (int s = 0; s < Tile<T>::NFRAG; ++s) {
+    for (int s = 0; s < NF; ++s) {
         const int off = (s * 2 + (lane >> 5)) * Tile<T>::EPC;
-        kf[s] = frag_scale<T>(*(const F*)(base + D + (int64_t)krow * ldqkv + off), sl2);
+        kf[s] = *(const F*)(base + D + (int64_t)krow * ldqkv + off);
         vf[s] = *(const F*)(base + 2 * D + (int64_t)krow * ldqkv + off);
     }
+    LaneOff<T> lo;
+    lane_offsets<T>(lo, lane);
+    uint32_t voq[LaneOff<T>::PER_WAVE], voo[LaneOff<T>::PER_WAVE];
+    stage_offsets<T>(voq, ldbq, TROWS, wave, lane);
+    stage_offsets<T>(voo, ldbo, TROWS, wave, lane);
     f32x16 dk[2] = {acc_splat(0.f), acc_splat(0.f)}, dv[2] = {acc_splat(0.f), acc_splat(0.f)};
 
     const int ntiles = (nq + TROWS - 1) / TROWS;               // only queries < nq carry a gradient
-    constexpr int STAGE = 2 * Tile<T>::BYTES + 2 * TROWS * 4;   // Q tile, dO tile, -lse*log2e [64], -delta [64]
-    auto stage = [&](int buf, int qt) {
+    constexpr int STAGE = 2 * TB + 2 * TROWS * 4;               // Q tile, dO tile, -lse*log2e [64], -delta [64]
+    auto stage = [&](int buf, int qt, const uint32_t (&vq)[LaneOff<T>::PER_WAVE], const uint32_t (&vo)[LaneOff<T>::PER_WAVE]) {
         char* sb = smem + buf * STAGE;
-        stage_tile<T>(sb, base, ldqkv, qt * TROWS, N, wave, lane);
-        stage_tile<T>(sb + Tile<T>::BYTES, dobase, ldo, qt * TROWS, nq, wave, lane);
+        stage_tile_off<T>(sb, (const char*)base + (int64_t)qt * TROWS * ldbq, vq, wave);
+        stage_tile_off<T>(sb + TB, (const char*)dobase + (int64_t)qt * TROWS * ldbo, vo, wave);
         // both per-query scalars come from the dQ kernel's workspace in the form the score chains take as C operand
-        if (wave == 0) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES), ws + plane + (int64_t)bh * nq, qt * TROWS, nq, lane);
-        if (wave == 1) stage_f32x64((float*)(sb + 2 * Tile<T>::BYTES) + TROWS, ws + (int64_t)bh * nq, qt * TROWS, nq, lane);
+        if (wave == 0) stage_f32x64((float*)(sb + 2 * TB), ws + plane + (int64_t)bh * nq, qt * TROWS, nq, lane);
+        if (wave == 1) stage_f32x64((float*)(sb + 2 * TB) + TROWS, ws + (int64_t)bh * nq, qt * TROWS, nq, lane);
+    };
+    auto stage_last = [&](int buf) {
+        uint32_t vq[LaneOff<T>::PER_WAVE], vo[LaneOff<T>::PER_WAVE];
+        const int lim = nq - 1 - (ntiles - 1) * TROWS;
+        stage_offsets<T>(vq, ldbq, lim, wave, lane);
+        stage_offsets<T>(vo, ldbo, lim, wave, lane);
+        stage(buf, ntiles - 1, vq, vo);
     };
     // one block of 32 queries against this wave's 32 keys
     auto block = [&](auto last_tag, int qt, int qb) {
         constexpr bool LAST = decltype(last_tag)::value;
         const char* sQ = smem + (qt & 1) * STAGE;
-        const char* sDO = sQ + Tile<T>::BYTES;
-        const float* sLse = (const float*)(sQ + 2 * Tile<T>::BYTES);
+        const char* sDO = sQ + TB;
+        const float* sLse = (const float*)(sQ + 2 * TB);
         const float* sDelta = sLse + TROWS;
-        // C operands: accumulator rows 4g..4g+3 are the 4 consecutive queries 8g + 4*(lane>>5) + {0..3}
-        f32x16 sa, dpa;
+        // per-query offsets: accumulator rows 4g..4g+3 are the 4 consecutive queries 8g + 4*(lane>>5) + {0..3}
+        f32x16 sa, dpa, nl;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ql = qb * 32 + 8 * g + 4 * (lane >> 5);
-            const f32x4 nl = *(const f32x4*)(sLse + ql), dl = *(const f32x4*)(sDelta + ql);
+            const f32x4 a = *(const f32x4*)(sLse + ql), d = *(const f32x4*)(sDelta + ql);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sa[4 * g + e] = nl[e]; dpa[4 * g + e] = dl[e]; }
+            for (int e = 0; e < 4; ++e) { nl[4 * g + e] = a[e]; dpa[4 * g + e] = d[e]; }
         }
-        // S'[q][key] = Q (K sl2)^T - lse ; dP'[q][key] = dO V^T - delta   (A rows = q, B cols = key = lane)
+        // S'[q][key] = (Q sl2) K^T - lse ; dP'[q][key] = dO V^T - delta   (A rows = q, B cols = key = lane)
+        if constexpr (PRE) {
+            sa = nl;
 #pragma unroll
-        for (int st = 0; st < Tile<T>::NFRAG; ++st) {
-            mma32<T>(sa, row_frag<T>(sQ, qb * 32 + (lane & 31), st, lane), kf[st]);
-            mma32<T>(dpa, row_frag<T>(sDO, qb * 32 + (lane & 31), st, lane), vf[st]);
+            for (int st = 0; st < NF; ++st) {
+                mma32<T>(sa, row_frag_off<T>(sQ, lo, qb * 32, st), kf[st]);
+                mma32<T>(dpa, row_frag_off<T>(sDO, lo, qb * 32, st), vf[st]);
+            }
+        } else {
+            mma32_first<T>(sa, row_frag_off<T>(sQ, lo, qb * 32, 0), kf[0]);
+            mma32<T>(dpa, row_frag_off<T>(sDO, lo, qb * 32, 0), vf[0]);
+#pragma unroll
+            for (int st = 1; st < NF; ++st) {
+                mma32<T>(sa, row_frag_off<T>(sQ, lo, qb * 32, st), kf[st]);
+                mma32<T>(dpa, row_frag_off<T>(sDO, lo, qb * 32, st), vf[st]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[r] = fmaf(sa[r], sl2, nl[r]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -788,13 +596,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 if (qt * TROWS + qb * 32 + acc_row(r, lane) >= nq) { sa[r] = 0.f; dpa[r] = 0.f; }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
-        constexpr int NS = AccSteps<T>::N;
         F cf[2][4];
         auto issue = [&](int slot, int st) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                cf[slot][db] = col_frag<T>(sDO, qb * 32, st, db * 32, lane);
-                cf[slot][2 + db] = col_frag<T>(sQ, qb * 32, st, db * 32, lane);
+                cf[slot][db] = col_frag_off<T>(sDO, lo, qb * 32, st, db, lane);
+                cf[slot][2 + db] = col_frag_off<T>(sQ, lo, qb * 32, st, db, lane);
             }
         };
         issue(0, 0);
@@ -814,11 +621,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             }
         }
     };
-    stage(0, 0);
+    if (ntiles == 1) stage_last(0);
+    else stage(0, 0, voq, voo);
     for (int qt = 0; qt < ntiles - 1; ++qt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        stage((qt + 1) & 1, qt + 1);
+        if (qt + 2 < ntiles) stage((qt + 1) & 1, qt + 1, voq, voo);
+        else stage_last((qt + 1) & 1);
         if (!active) continue;          // all 32 keys of this wave are past N: stage and meet barriers only
         block(std::false_type{}, qt, 0);
         block(std::false_type{}, qt, 1);
@@ -829,26 +638,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const int qt = ntiles - 1;
         block(std::true_type{}, qt, 0);
         if (qt * TROWS + 32 < nq) block(std::true_type{}, qt, 1);      // else: the second 32 queries do not exist
-    }
-    __syncthreads();
-    if (k0 < N) {
-        float* slab = (float*)smem + wave * (32 * 65);
         T* out = dqkv + (int64_t)b * N * lddqkv + h * HD;
-        store_rows_T<T>(slab, dk, scale, out + D, lddqkv, k0, min(32, N - k0), lane);
-        store_rows_T<T>(slab, dv, 1.0f, out + 2 * D, lddqkv, k0, min(32, N - k0), lane);
+        // PRE: the Q rows in memory are Q * scale * log2(e): dK = dS^T Q * scale = acc * ln 2
+        store_rows_direct<T>(dk, PRE ? LN2 : scale, out + D, lddqkv, k0, min(32, N - k0), lane);
+        store_rows_direct<T>(dv, 1.0f, out + 2 * D, lddqkv, k0, min(32, N - k0), lane);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, part 2: dQ.  Workgroup owns 128 queries (lane = query); keys stream through LDS.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? PA_ATTN_DQ_WAVES : 1))) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ o, const T* __restrict__ d_o, int ldo,
                                                           const float* __restrict__ lse, float* __restrict__ delta, int64_t plane,
                                                           T* __restrict__ dqkv, int lddqkv, int H, int N, int nq, float scale, int nblk, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using F = typename Frag<T>::type;
+    constexpr int NF = Tile<T>::NFRAG, NS = AccSteps<T>::N, TB = Tile<T>::BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int blk, bh;
@@ -863,17 +670,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const int qrow = min(q, nq - 1);
     const bool active = q0 < nq;                                // wave-uniform
     const float sl2 = scale * LOG2E;
+    const int ldb = ldqkv * (int)sizeof(T);
 
-    F qf[Tile<T>::NFRAG], dof[Tile<T>::NFRAG];                  // qf = Q * scale * log2(e)
+    F qf[NF], dof[NF];
     float dlt = 0.f;
     {
         // delta[q] = sum_d dO[q][d] O[q][d]: this lane holds half of row q of dO as fragments already; the same
         // chunks of O are read once here, and the row sum is published for the dK/dV kernel (launched after)
         const T* obase = o + (int64_t)b * nq * ldo + h * HD;
 #pragma unroll
-        for (int s = 0; s < Tile<T>::NFRAG; ++s) {
+        for (int s = 0; s < NF; ++s) {
             const int off = (s * 2 + (lane >> 5)) * Tile<T>::EPC;
-            qf[s] = frag_scale<T>(*(const F*)(base + (int64_t)qrow * ldqkv + off), sl2);
+            qf[s] = *(const F*)(base + (int64_t)qrow * ldqkv + off);
             dof[s] = *(const F*)(dobase + (int64_t)qrow * ldo + off);
             const F of = *(const F*)(obase + (int64_t)qrow * ldo + off);
 #pragma unroll
@@ -887,42 +695,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         delta[(int64_t)bh * nq + q] = -dlt;
         delta[plane + (int64_t)bh * nq + q] = -lse2;
     }
-    const f32x16 neglse = acc_splat(-lse2), negdl = acc_splat(-dlt);
+    // C operands of the two score chains: -lse stays in a block of 16 registers; -delta is splatted per chain (168
+    // registers = 3 waves per SIMD do not hold both blocks, and a spill inside the tile loop makes the compiler drain
+    // vmcnt -- i.e. wait for the next tile's LDS-DMA -- in front of the reload)
+    const f32x16 neglse = acc_splat(-lse2);
+    const float ndl = -dlt;
     f32x16 dq[2] = {acc_splat(0.f), acc_splat(0.f)};
+    LaneOff<T> lo;
+    lane_offsets<T>(lo, lane);
+    uint32_t voff[LaneOff<T>::PER_WAVE];
+    stage_offsets<T>(voff, ldb, TROWS, wave, lane);
 
     const int ntiles = (N + TROWS - 1) / TROWS;
-    auto stage = [&](int buf, int kt) {
-        char* sb = smem + buf * (2 * Tile<T>::BYTES);
-        stage_tile<T>(sb, base + D, ldqkv, kt * TROWS, N, wave, lane);
-        stage_tile<T>(sb + Tile<T>::BYTES, base + 2 * D, ldqkv, kt * TROWS, N, wave, lane);
+    const char* gK = (const char*)(base + D);
+    const char* gV = (const char*)(base + 2 * D);
+    auto stage = [&](int buf, int kt, const uint32_t (&vo)[LaneOff<T>::PER_WAVE]) {
+        char* sb = smem + buf * (2 * TB);
+        const int64_t row0 = (int64_t)kt * TROWS * ldb;
+        stage_tile_off<T>(sb, gK + row0, vo, wave);
+        stage_tile_off<T>(sb + TB, gV + row0, vo, wave);
+    };
+    auto stage_last = [&](int buf) {
+        uint32_t vt[LaneOff<T>::PER_WAVE];
+        stage_offsets<T>(vt, ldb, N - 1 - (ntiles - 1) * TROWS, wave, lane);
+        stage(buf, ntiles - 1, vt);
     };
     // one block of 32 keys against this wave's 32 queries
     auto block = [&](auto last_tag, int kt, int kb) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const char* sK = smem + (kt & 1) * (2 * Tile<T>::BYTES);
-        const char* sV = sK + Tile<T>::BYTES;
+        const char* sK = smem + (kt & 1) * (2 * TB);
+        const char* sV = sK + TB;
         f32x16 sa, dpa;
         // S'^T[key][q] = K (Q sl2)^T - lse ; dP'^T[key][q] = V dO^T - delta
-        mma32_c<T>(sa, row_frag<T>(sK, kb * 32 + (lane & 31), 0, lane), qf[0], neglse);
-        mma32_c<T>(dpa, row_frag<T>(sV, kb * 32 + (lane & 31), 0, lane), dof[0], negdl);
+        if constexpr (PRE) mma32_c<T>(sa, row_frag_off<T>(sK, lo, kb * 32, 0), qf[0], neglse);
+        else mma32_first<T>(sa, row_frag_off<T>(sK, lo, kb * 32, 0), qf[0]);
+        {
+            float t = ndl;
+            asm volatile("" : "+v"(t));                         // keep the splat inside the loop (not 16 hoisted registers)
+            dpa = acc_splat(t);
+        }
+        mma32<T>(dpa, row_frag_off<T>(sV, lo, kb * 32, 0), dof[0]);
 #pragma unroll
-        for (int st = 1; st < Tile<T>::NFRAG; ++st) {
-            mma32<T>(sa, row_frag<T>(sK, kb * 32 + (lane & 31), st, lane), qf[st]);
-            mma32<T>(dpa, row_frag<T>(sV, kb * 32 + (lane & 31), st, lane), dof[st]);
+        for (int st = 1; st < NF; ++st) {
+            mma32<T>(sa, row_frag_off<T>(sK, lo, kb * 32, st), qf[st]);
+            mma32<T>(dpa, row_frag_off<T>(sV, lo, kb * 32, st), dof[st]);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dpa[r] *= __builtin_amdgcn_exp2f(sa[r]);      // dS^T / scale
+        for (int r = 0; r < 16; ++r) dpa[r] *= __builtin_amdgcn_exp2f(PRE ? sa[r] : fmaf(sa[r], sl2, -lse2));      // dS^T / scale
         if (LAST && (N & (TROWS - 1))) {                        // keys beyond N: last tile only
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kt * TROWS + kb * 32 + acc_row(r, lane) >= N) dpa[r] = 0.f;
         }
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-        constexpr int NS = AccSteps<T>::N;
         F cf[2][2];
         auto issue = [&](int slot, int st) {
 #pragma unroll
-            for (int db = 0; db < 2; ++db) cf[slot][db] = col_frag<T>(sK, kb * 32, st, db * 32, lane);
+            for (int db = 0; db < 2; ++db) cf[slot][db] = col_frag_off<T>(sK, lo, kb * 32, st, db, lane);
         };
         issue(0, 0);
 #pragma unroll
@@ -938,11 +767,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             for (int db = 0; db < 2; ++db) mma32<T>(dq[db], cf[st & 1][db], dsf);
         }
     };
-    stage(0, 0);
+    if (ntiles == 1) stage_last(0);
+    else stage(0, 0, voff);
     for (int kt = 0; kt < ntiles - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        stage((kt + 1) & 1, kt + 1);
+        if (kt + 2 < ntiles) stage((kt + 1) & 1, kt + 1, voff);
+        else stage_last((kt + 1) & 1);
         if (!active) continue;          // all 32 queries of this wave are past nq
         block(std::false_type{}, kt, 0);
         block(std::false_type{}, kt, 1);
@@ -953,41 +784,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const int kt = ntiles - 1;
         block(std::true_type{}, kt, 0);
         if (kt * TROWS + 32 < N) block(std::true_type{}, kt, 1);       // else: the second 32 keys do not exist
+        // gradient with respect to the TRUE q in both modes (the upstream linear layer is differentiated as unscaled)
+        store_rows_direct<T>(dq, scale, dqkv + (int64_t)b * N * lddqkv + h * HD, lddqkv, q0, min(32, nq - q0), lane);
     }
-    __syncthreads();
-    if (q0 < nq)
-        store_rows_T<T>((float*)smem + wave * (32 * 65), dq, scale, dqkv + (int64_t)b * N * lddqkv + h * HD,
-                        lddqkv, q0, min(32, nq - q0), lane);
 }
 
-template <typename T> static size_t fwd_lds() { return std::max<size_t>(4 * Tile<T>::BYTES, SLAB_BYTES); }
-template <typename T> static size_t dkdv_lds() { return std::max<size_t>(2 * (2 * Tile<T>::BYTES + 2 * TROWS * 4), SLAB_BYTES); }
+template <typename T> static size_t fwd_lds() { return 4 * Tile<T>::BYTES; }   // K/V double buffer
+template <typename T> static size_t dkdv_lds() { return 2 * (2 * Tile<T>::BYTES + 2 * TROWS * 4); }
 
 template <typename T>
 static int attention_fwd_t(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
-                           float scale, hipStream_t st) {
+                           float scale, int flags, hipStream_t st) {
     const int nblk = (int)cdiv(nq, 128);
-    if (PA_ATTN_PIPE)
-        hipLaunchKernelGGL(attn_fwd_pipe_kernel<T>, dim3(attn_grid(nblk, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
-                           (T*)o, ldo, lse, H, N, nq, scale, nblk, B * H);
+    const dim3 grid(attn_grid(nblk, B * H)), block(256);
+    if (flags & PA_ATTN_Q_PRESCALED)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, true>), grid, block, fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, nq, scale, nblk, B * H);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(attn_grid(nblk, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o,
-                           ldo, lse, H, N, nq, scale, nblk, B * H);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), grid, block, fwd_lds<T>(), st, (const T*)qkv, ldqkv, (T*)o, ldo, lse, H, N, nq, scale, nblk, B * H);
     return check_launch();
 }
 
-template <typename T>
+template <typename T, bool PRE>
 static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo, const float* lse,
                            float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq, float scale, hipStream_t st) {
     // dQ first: it also fills the workspace the dK/dV kernel consumes, two planes of B*H*nq floats:
-    // rowsum(dO * O) * scale and -lse * log2(e)
+    // -rowsum(dO * O) and -lse * log2(e)
     const int64_t plane = (int64_t)B * H * nq;
     const int nblkq = (int)cdiv(nq, 128), nblkk = (int)cdiv(N, 128);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(attn_grid(nblkq, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PRE>), dim3(attn_grid(nblkq, B * H)), dim3(256), fwd_lds<T>(), st, (const T*)qkv, ldqkv,
                        (const T*)o, (const T*)d_o, ldo, lse, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale, nblkq, B * H);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(attn_grid(nblkk, B * H)), dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, PRE>), dim3(attn_grid(nblkk, B * H)), dim3(256), dkdv_lds<T>(), st, (const T*)qkv, ldqkv,
                        (const T*)d_o, ldo, delta, plane, (T*)dqkv, lddqkv, H, N, nq, scale, nblkk, B * H);
     return check_launch();
 }
@@ -1001,29 +829,29 @@ static bool attn_args_ok(int ld, int dtype) {
     return (ld * es) % 16 == 0;
 }
 
-#ifdef PA_ATTN_PROBE
-// probe library only: read (and clear) the phase-cycle sums of the plain forward kernel
-extern "C" int pa_attn_probe_read(unsigned long long* host_out) {   // PROBE_WAVES * 8 values
-    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pa::g_attn_probe), sizeof(unsigned long long) * pa::PROBE_WAVES * 8);
-    return e == hipSuccess ? PA_OK : pa::set_hip_error(e);
-}
-#endif
+extern "C" int64_t pa_attention_bwd_ws_floats(int B, int H, int nq) { return 2 * (int64_t)B * H * nq; }
 
 extern "C" int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
-                                float scale, int dtype, void* stream) {
-    if (!qkv || !o || !lse || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N) return PA_EINVAL;
+                                float scale, int dtype, int flags, void* stream) {
+    if (!qkv || !o || !lse || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N || (flags & ~PA_ATTN_Q_PRESCALED)) return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype)) return PA_EUNSUPPORTED;
-    if (dtype == PA_BF16) return attention_fwd_t<bf16>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, (hipStream_t)stream);
-    if (dtype == PA_F32) return attention_fwd_t<float>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, (hipStream_t)stream);
+    if (dtype == PA_BF16) return attention_fwd_t<bf16>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, flags, (hipStream_t)stream);
+    if (dtype == PA_F32) return attention_fwd_t<float>(qkv, ldqkv, o, ldo, lse, B, H, N, nq, scale, flags, (hipStream_t)stream);
     return PA_EINVAL;
 }
 
 extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
                                 const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
-                                float scale, int dtype, void* stream) {
-    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N) return PA_EINVAL;
+                                float scale, int dtype, int flags, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N || (flags & ~PA_ATTN_Q_PRESCALED)) return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype) || !attn_args_ok(lddqkv, dtype)) return PA_EUNSUPPORTED;
-    if (dtype == PA_BF16) return attention_bwd_t<bf16>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, (hipStream_t)stream);
-    if (dtype == PA_F32) return attention_bwd_t<float>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, (hipStream_t)stream);
+    const bool pre = flags & PA_ATTN_Q_PRESCALED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PA_BF16)
+        return pre ? attention_bwd_t<bf16, true>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st)
+                   : attention_bwd_t<bf16, false>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st);
+    if (dtype == PA_F32)
+        return pre ? attention_bwd_t<float, true>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st)
+                   : attention_bwd_t<float, false>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st);
     return PA_EINVAL;
 }

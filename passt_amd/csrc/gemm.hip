@@ -97,6 +97,13 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
     const int ncol = n0 + wc * 64 + ecol;
     const bool colok = ncol < a.N;               // N % 8 == 0: the lane's 8-vector is all in or all out
+    // PA_EPI_STORE: (acc + bias) * colscale for the columns below colscale_n (a multiple of 64)
+    float cs = 1.f, bias8s[8];
+    if constexpr (EPI == PA_EPI_STORE) {
+        if (ncol < a.colscale_n) cs = a.colscale;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8s[e] = bias8[e] * cs;
     constexpr int P = aux_depth<EPI, TM>();
     constexpr int NV = (EPI == PA_EPI_RESID || sizeof(T) == 4) ? 2 : 1;     // 16-byte vectors per 8 aux elements
     f32x4 xr[P > 0 ? P : 1][4][NV];
@@ -152,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const pa_gemm_args& a, f32x16 (&ac
             const f32x4 lo = *(const f32x4*)(slab + row * 68 + ecol);
             const f32x4 hi = *(const f32x4*)(slab + row * 68 + ecol + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[it][e] = lo[e] + bias8[e]; v[it][4 + e] = hi[e] + bias8[4 + e]; }
+            for (int e = 0; e < 4; ++e) { v[it][e] = fmaf(lo[e], cs, bias8s[e]); v[it][4 + e] = fmaf(hi[e], cs, bias8s[4 + e]); }
         }
         if constexpr (P > 0) {
 #pragma unroll
@@ -437,6 +444,12 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
     if constexpr (EPI != PA_EPI_DGELU) {
         if (bias_row) { b2[0] = bias_row[wc * 64 + c]; b2[1] = bias_row[wc * 64 + 32 + c]; }
     }
+    // PA_EPI_STORE: (acc + bias) * colscale for the columns below colscale_n (a multiple of 64: uniform per wave tile);
+    // the scale rides in the multiply-add that used to be the bias add
+    float cs = 1.f;
+    if constexpr (EPI == PA_EPI_STORE) {
+        if (nb < a.colscale_n) { cs = a.colscale; b2[0] *= cs; b2[1] *= cs; }
+    }
     const bool colok = nb + g * 8 < a.N;                              // N % 8 == 0: all 8 columns of the lane in or out
     const uint32_t ld2 = (uint32_t)a.ldolp * 2u;
     const auto ors = tile_rsrc((const char*)a.out_lp + ((int64_t)mb * a.ldolp + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp + (a.N - nb)) * 2);
@@ -491,6 +504,7 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 f32x2 v = {acc[i][j][2 * k] + b2[j], acc[i][j][2 * k + 1] + b2[j]};
+                if constexpr (EPI == PA_EPI_STORE) v = f32x2{fmaf(acc[i][j][2 * k], cs, b2[j]), fmaf(acc[i][j][2 * k + 1], cs, b2[j])};
                 if constexpr (EPI == PA_EPI_DGELU) {
                     uint32_t xw;
                     if constexpr (BLK) xw = xblk[j * 2 + (k >> 2)][k & 3];
@@ -2103,6 +2117,7 @@ extern "C" int pa_gemm_nt(const pa_gemm_args* a, void* stream) {
     if (a->resid && a->ldr % 4) return PA_EUNSUPPORTED;
     if (a->aux && a->ldaux % 8) return PA_EUNSUPPORTED;
     if (a->colsum_out && (a->epilogue != PA_EPI_DGELU || !a->colsum_ws)) return PA_EINVAL;
+    if (a->colscale_n && (a->epilogue != PA_EPI_STORE || a->colscale_n < 0 || a->colscale_n % 64)) return PA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == PA_BF16) return dispatch_gemm<bf16>(*a, st);
     if (a->dtype == PA_F32) return dispatch_gemm<float>(*a, st);

@@ -171,7 +171,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
 # ---- GEMM ------------------------------------------------------------------------------------
 def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
             out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None,
-            colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0):
+            colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0, colscale_n=0, colscale=1.0):
     """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h.  EPI_DGELU can also return the
     column sums of its output (colsum_out [N] f32; colsum_ws from gemm_colsum_ws)."""
     a = GemmArgs()
@@ -196,6 +196,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.split_k = split_k
     a.tune = GEMM_TUNE
     a.reserved = GEMM_RESERVED | flags
+    a.colscale_n, a.colscale = colscale_n, colscale
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
     if GEMM_PROFILE is None:
         check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
@@ -216,10 +217,11 @@ def gemm_colsum_ws(M, N, device, ws=None):
     return ws
 
 
-def linear(x_lp, W_lp, bias, dtype):
-    """out_lp[M][N] = x W^T + b"""
+def linear(x_lp, W_lp, bias, dtype, colscale_n=0, colscale=1.0):
+    """out_lp[M][N] = x W^T + b; the first colscale_n output columns times colscale (the qkv Linear hands attention
+    q * scale * log2(e): ATTN_Q_PRESCALED)"""
     out = torch.empty((x_lp.shape[0], W_lp.shape[0]), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
-    gemm_nt(x_lp, W_lp, dtype, EPI_STORE, bias=bias, out_lp=out)
+    gemm_nt(x_lp, W_lp, dtype, EPI_STORE, bias=bias, out_lp=out, colscale_n=colscale_n, colscale=colscale)
     return out
 
 
@@ -464,8 +466,13 @@ def colsum_f32(x, out_f32, accumulate=False):
 
 
 # ---- attention -------------------------------------------------------------------------------
-def attention_fwd(qkv, B, H, N, scale, nq=None):
-    """o[(b*nq+q)][H*64], lse[(b*H+h)*nq+q] for the first nq queries of every sequence (nq=None: all N)."""
+ATTN_Q_PRESCALED = 1          # include/passt_amd.h PA_ATTN_Q_PRESCALED
+LOG2E = 1.4426950408889634
+
+
+def attention_fwd(qkv, B, H, N, scale, nq=None, flags=0):
+    """o[(b*nq+q)][H*64], lse[(b*H+h)*nq+q] for the first nq queries of every sequence (nq=None: all N).
+    flags=ATTN_Q_PRESCALED: the q third of qkv holds q * scale * log2(e)."""
     dtype = PA_DTYPE[qkv.dtype]
     nq = N if nq is None else nq
     D = H * 64
@@ -473,24 +480,24 @@ def attention_fwd(qkv, B, H, N, scale, nq=None):
     lse = torch.empty((B * H * nq,), device=qkv.device, dtype=torch.float32)
     _timed("attn_fwd", 4.0 * nq * N * 64 * B * H,
            lambda: check(_lib.load().pa_attention_fwd(_p(qkv, None, True), qkv.stride(0), _p(o), o.stride(0), _p(lse), B, H, N, nq,
-                                                      scale, dtype, _stream()), "pa_attention_fwd"))
+                                                      scale, dtype, flags, _stream()), "pa_attention_fwd"))
     return o, lse
 
 
-def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None):
+def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None, flags=0):
     """dqkv [B*N][3D]; with nq < N (o, d_o, lse compact) the Q third is zero outside the first nq rows."""
     dtype = PA_DTYPE[qkv.dtype]
     nq = N if nq is None else nq
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(2 * lse.numel(), device=lse.device, dtype=torch.float32)
     lib = _lib.load()
+    delta = torch.empty(lib.pa_attention_bwd_ws_floats(B, H, nq), device=lse.device, dtype=torch.float32)
     if nq < N:
         es = qkv.element_size()
         check(lib.pa_zero2d(_p(dqkv), dqkv.stride(0) * es, H * 64 * es, B * N, _stream()), "pa_zero2d")
     _timed("attn_bwd", 10.0 * nq * N * 64 * B * H,      # five N x N x 64 products: S, dP, dV, dK, dQ
            lambda: check(lib.pa_attention_bwd(_p(qkv, None, True), qkv.stride(0), _p(o, qkv.dtype, True), _p(d_o, qkv.dtype, True),
                                               o.stride(0), _p(lse, torch.float32), _p(delta), _p(dqkv), dqkv.stride(0), B, H, N, nq,
-                                              scale, dtype, _stream()), "pa_attention_bwd"))
+                                              scale, dtype, flags, _stream()), "pa_attention_bwd"))
     return dqkv
 
 

@@ -268,9 +268,13 @@ def passt_forward(model, x, save):
     for bi, blk in enumerate(model.blocks):
         last = bi == nblk - 1
         ln1, mean1, rstd1 = ops.layernorm_fwd(xs, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, dt, save)
-        qkv = ops.linear(ln1, st.get(blk.attn.qkv.weight, dt, False), blk.attn.qkv.bias, dt)
+        # the q third leaves the GEMM as q * scale * log2(e) (one rounding): attention takes "score - row reference"
+        # straight from the matrix pipe (ATTN_Q_PRESCALED); every gradient stays the gradient of the unscaled Linear
+        qkv = ops.linear(ln1, st.get(blk.attn.qkv.weight, dt, False), blk.attn.qkv.bias, dt,
+                         colscale_n=D, colscale=scale * ops.LOG2E)
+        aflags = ops.ATTN_Q_PRESCALED
         if not last:
-            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale)
+            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale, flags=aflags)
             x_res = xs
         else:
             # PREFIX-ONLY TAIL.  The network output reads the last block at the cls/dist rows only
@@ -278,7 +282,7 @@ def passt_forward(model, x, save):
             # 2 queries (keys/values still span every token), then proj / LN2 / MLP on [2B, D].  Exact, not an
             # approximation: the reference computes the other N-2 rows and discards them.
             pidx = _prefix_rows(model, B, Ntok, x.device)
-            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale, nq=2)
+            att, lse = ops.attention_fwd(qkv, B, H, Ntok, scale, nq=2, flags=aflags)
             x_res = ops.gather_rows(xs, pidx)
         x_mid = ops.linear_resid(att, st.get(blk.attn.proj.weight, dt, False), blk.attn.proj.bias, x_res, dt)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, dt, save)
@@ -412,11 +416,11 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         d_att = torch.empty_like(att)
         ops.gemm_nt(dx_lp, st.get(blk.attn.proj.weight, dt, True), dt, EPI_STORE, out_lp=d_att)
         if not last:
-            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"])
+            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"], flags=ops.ATTN_Q_PRESCALED)
             dres = dx
         else:
             # only 2 queries per sequence carry a gradient; the residual gradient lives on the prefix rows only
-            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"], nq=2)
+            d_qkv = ops.attention_bwd(qkv, att, d_att, lse, B, H, Ntok, ctx["scale"], nq=2, flags=ops.ATTN_Q_PRESCALED)
             dres = ops.scatter_rows_into_zeros(dx, _prefix_rows(model, B, Ntok, dx.device), M)
         d_ln1 = torch.empty_like(ln1)
         ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)

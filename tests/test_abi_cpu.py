@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
         assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.pa_abi_version() == 1
+    assert lib.pa_abi_version() == 2
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
     assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768
@@ -45,10 +45,11 @@ def test_ctypes_structs_match_the_c_layout():
 #include <stddef.h>
 #include "passt_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
          offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
          offsetof(pa_gemm_args, tune), sizeof(pa_mel_params), offsetof(pa_gemm_args, colsum_out),
-         offsetof(pa_gemm_args, colsum_accumulate), sizeof(pa_stage_desc));
+         offsetof(pa_gemm_args, colsum_accumulate), sizeof(pa_stage_desc), offsetof(pa_gemm_args, colscale_n),
+         offsetof(pa_gemm_args, colscale));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -58,7 +59,7 @@ int main(void) {
     G = _lib.GemmArgs
     got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
            G.tune.offset, ctypes.sizeof(_lib.MelParams), G.colsum_out.offset, G.colsum_accumulate.offset,
-           ctypes.sizeof(_lib.StageDesc)]
+           ctypes.sizeof(_lib.StageDesc), G.colscale_n.offset, G.colscale.offset]
     assert got == [int(v) for v in out]
 
 
@@ -235,3 +236,20 @@ def test_host_side_queries_answer_without_a_gpu():
     assert lib.pa_gemm_blocked_pre_ok(128, 3072, 768) == 0
     assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3080, 768) == 0
     assert lib.pa_gemm_blocked_pre_ok(0, 3072, 768) == 0
+
+
+def test_attention_isa_never_touches_in_flight_lds_fragments():
+    """tools/check_lds_asm.py on the compiled attention kernels: the asm-issued transposed LDS reads are settled by counted
+    waits the compiler does not know about, so no instruction may read or overwrite their destination registers before the
+    wait (round 3: a register copy at a control-flow merge did, and output rows were sporadically garbage at B = 64)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "passt_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "attention.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                        "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                        os.path.join(src, "attention.hip"), "-o", out], check=True, capture_output=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_asm.py"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -48,9 +48,9 @@ def main():
         g = torch.Generator(device="cuda").manual_seed(1)
         qkv = (torch.randn(B * N, 3 * D, device="cuda", generator=g)).to(dt)
         d_o = torch.randn(B * N, D, device="cuda", generator=g).to(dt)
-        o, lse = ops.attention_fwd(qkv, B, H, N, 0.125)
-        tf = timeit(lambda: ops.attention_fwd(qkv, B, H, N, 0.125), args.iters)
-        tb = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, B, H, N, 0.125), args.iters)
+        o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED)
+        tf = timeit(lambda: ops.attention_fwd(qkv, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED), args.iters)
+        tb = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED), args.iters)
         ff, fb = 4.0 * N * N * 64 * B * H, 10.0 * N * N * 64 * B * H
         print(json.dumps({"lib": args.tag, "shape": shp, "dtype": args.dtype, "fwd_us": round(tf * 1e6, 1),
                           "bwd_us": round(tb * 1e6, 1), "fwd_tflops": round(ff / tf / 1e12, 1),
