@@ -131,6 +131,58 @@ def cpu_baseline(budget_s=12.0, threads=None):
                       f"restatement of the reference, {threads} threads of {os.cpu_count()} hw threads), {dt:.1f} s"}
 
 
+def cpu_baseline_forward(budget_s=10.0, threads=None):
+    """north_star: "the reference CPU forward timed on the same host (core count stated)" = BASELINE config #1 exactly:
+    passt_s_swa_p16_128_ap476, eval-mode forward of batch 2 synthetic 10 s @ 32 kHz waveforms, mel front end + network,
+    no patchout (1190 tokens), fp32, on the oracle (the port of the reference; /root/reference is not on the GPU box)."""
+    from oracle import detgen
+    from oracle import passt_oracle as O
+    threads = threads or min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.make_cfg()
+    sd = O.to_torch(detgen.passt_state_dict(cfg, 1))
+    B = 2
+    wave = torch.from_numpy(detgen.uniform(2, "wave", (B, CLIP_SAMPLES), -0.1, 0.1))
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        while True:
+            t0 = time.time()
+            mel = O.mel_frontend(wave, training=False, fmin_aug_range=10, fmax_aug_range=2000)
+            O.passt_forward(sd, mel[:, None, :, :998], cfg, training=False)
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget_s or len(times) >= 40:
+                break
+    used = times[1:] if len(times) > 1 else times
+    dt = sum(used)
+    return {"value": round(len(used) * B / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"BASELINE config #1: {len(used)} eval-mode forwards of batch {B} x 10 s @ 32 kHz waveforms (mel front end + "
+                      f"network, no patchout, 1190 tokens, fp32 torch CPU restatement of the reference, {threads} threads of "
+                      f"{os.cpu_count()} hw threads), {dt:.1f} s"}
+
+
+def _sha16(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def committed_traffic(name, sources):
+    """HBM bytes per launch from a committed PMC profile (the counters cannot be read inside an un-profiled run).  The JSON
+    records the sha256 of the kernel sources it was measured on; if they changed since, the number is STALE and is not
+    reported (traffic = null and the reason in traffic_source) -- re-run tools/collect_profiles.sh."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.isfile(path):
+        return None, f"profiles/{name} missing: run tools/collect_profiles.sh"
+    with open(path) as f:
+        tj = json.load(f)
+    now = {os.path.basename(p): _sha16(os.path.join(ROOT, p)) for p in sources}
+    if tj.get("source_sha16") != now:
+        return None, (f"STALE: profiles/{name} was measured on {tj.get('source_sha16')}, the kernels are now {now}; "
+                      "re-run tools/collect_profiles.sh")
+    return tj["hbm_bytes_per_launch"], f"profiles/{name} (" + tj.get("method", "rocprofv3 --pmc") + ")"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +191,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=list(CONFIGS), help="BASELINE.json configuration (default c2 = the metric's)")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the configuration's)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce")
+    ap.add_argument("--transport", default="torch", choices=["torch", "rccl_abi"],
+                    help="N > 1: torch.distributed (nccl = RCCL) or the library's own pa_comm_* entry points")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events (measures their cost)")
@@ -184,7 +238,7 @@ def main():
     net.overlap_wgrad = args.overlap_wgrad
     # TrainStep broadcasts rank 0's parameters itself (identical replicas)
     ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
-                   loss=cfgd["loss"], comm_dtype=args.comm_dtype)
+                   loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport)
     B = args.batch or cfgd["batch"]
     frames = 998 if cfgd["clip"] == CLIP_SAMPLES else 1 + (cfgd["clip"] - 1) // 320     # --no-mel: the reference's speed-test shape
     if args.no_mel:
@@ -222,6 +276,39 @@ def main():
     elapsed = float(elapsed.item())
     loss_v = float(loss.item())
     assert np.isfinite(loss_v), "non-finite loss"
+
+    # ---- outside the timed region -------------------------------------------------------------------------------
+    # (a) N > 1: MEASURED per-bucket all-reduce (HIP events: launch -> released, and how long the compute stream was
+    #     blocked on it) of one extra instrumented step, next to the modelled curve
+    allreduce = None
+    if world > 1:
+        ts.reducer.start_timing()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ts.step(x, y)
+        barrier()
+        buckets = ts.reducer.timing_summary()
+        ts.reducer.timing = None
+        if rank == 0:
+            allreduce = {"kind": "MEASURED on this run (one instrumented step after the timed region, rank 0)",
+                         "transport": args.transport, "wire_dtype": args.comm_dtype, "buckets": buckets,
+                         "bytes_per_step": sum(b["bytes"] for b in buckets),
+                         "exposed_wait_ms_per_step": round(sum(b["exposed_wait_ms"] for b in buckets), 4),
+                         "bus_GBps_min_max": [min(b["bus_GBps"] for b in buckets), max(b["bus_GBps"] for b in buckets)] if buckets else None}
+    # (b) the parity mode (exact-f32 MFMA, <= 3e-6 of the fp32 reference: the bound north_star states) trains this fast
+    parity_clips = None
+    if world == 1 and args.config == "c2" and args.precision == "bf16" and not args.no_cpu_baseline:
+        net.precision = "fp32"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ts.step(x, y)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for _ in range(3):
+                ts.step(x, y)
+            torch.cuda.synchronize()
+            parity_clips = round(3 * B / (time.perf_counter() - tp0), 1)
+        net.precision = args.precision
 
     if rank == 0:
         clips = world * B * args.steps
@@ -274,27 +361,19 @@ def main():
             # north_star: "rocprof-reported HBM GB/s for the front end": live number here, PMC traffic in profiles/
             if "mel" in side:
                 nm, msm, wm = side["mel"]
-                mt = None
-                mpath = os.path.join(ROOT, "profiles", "r02_mel_traffic.json")
-                if os.path.isfile(mpath) and args.config == "c2" and B == 64:
-                    with open(mpath) as f:
-                        mt = json.load(f).get("hbm_bytes_per_launch")
+                mt, mt_src = (committed_traffic("r03_mel_traffic.json", ["passt_amd/csrc/mel.hip"])
+                              if (args.config == "c2" and B == 64) else (None, "only collected for config c2, B = 64"))
                 out["frontend"] = {"bound": "hbm", "kernel": "pa::mel_frontend_kernel (STFT + mel + log + SpecAugment, one launch)",
                                    "avg_us": round(1e3 * msm / nm, 2), "achieved": round(wm / msm / 1e6, 1), "peak": HBM_PEAK_GBPS,
                                    "unit": "GB/s", "frac": round(wm / msm / 1e6 / HBM_PEAK_GBPS, 4),
-                                   "algorithmic_bytes_per_launch": round(wm / nm), "traffic": mt,
+                                   "algorithmic_bytes_per_launch": round(wm / nm), "traffic": mt, "traffic_source": mt_src,
                                    "time_share_of_step": round(msm / n_prof_steps / ms_step, 4)}
             # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
             # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
             # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
-            traffic, traffic_src = None, None
-            for tname in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
-                tpath = os.path.join(ROOT, "profiles", tname)
-                if os.path.isfile(tpath) and args.config == "c2" and B == 64 and args.precision == "bf16":
-                    with open(tpath) as f:
-                        tj = json.load(f)
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tname} (" + tj["method"] + ")"
-                    break
+            traffic, traffic_src = (committed_traffic("r03_gemm_traffic.json", ["passt_amd/csrc/gemm.hip"])
+                                    if (args.config == "c2" and B == 64 and args.precision == "bf16")
+                                    else (None, "only collected for config c2, B = 64, bf16"))
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -312,6 +391,11 @@ def main():
                                 "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes())}
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline_forward"] = cpu_baseline_forward()
+        if parity_clips is not None:
+            out["parity_mode_clips_s"] = parity_clips     # same step, precision="fp32": what meets the <= 1e-3 parity bound
+        if allreduce is not None:
+            out["allreduce_measured"] = allreduce
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

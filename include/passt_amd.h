@@ -81,6 +81,8 @@ int pa_mel_frontend_fwd(const float* wave, int B, int L, const float* window, co
  * ------------------------------------------------------------------------------------------ */
 /* out[i] = (dtype) in[i] */
 int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, void* stream);
+/* out[i] = (float) in[i], in of `dtype` (the bf16 gradient wire of the data-parallel reducer, passt_amd/ddp.py) */
+int pa_convert_to_f32(const void* in, int dtype, float* out, int64_t n, void* stream);
 /* Batched form of the two calls below, for refreshing every GEMM-ready weight copy after an optimizer
  * step in ONE launch: entry e reads src[rows][cols] (f32, contiguous) and writes, where non-NULL,
  * dst[rows][cols] (straight cast) and dst_t[cols][rows] (transposed), both of `dtype` and contiguous.

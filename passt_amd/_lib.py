@@ -50,6 +50,7 @@ SIGNATURES = {
     "pa_mel_num_frames": (i32, [i32, i32]),
     "pa_mel_frontend_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, C.POINTER(MelParams), vp]),
     "pa_convert_f32": (i32, [vp, vp, i64, i32, vp]),
+    "pa_convert_to_f32": (i32, [vp, i32, vp, i64, vp]),
     "pa_transpose": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pa_stage_weights": (i32, [vp, i32, i32, i32, vp]),
     "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),

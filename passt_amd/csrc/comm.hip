@@ -3,7 +3,25 @@
 // all-reduce).  RCCL is resolved at RUN time (dlopen, preferring a copy the process has already loaded, e.g. torch's):
 // libpasst_amd.so itself has no link-time dependency on it, and a single-GPU user never touches it.
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
+// RCCL is dlopen'ed at run time; its header is only needed for a handful of types.  A ROCm install without the RCCL
+// development headers still builds the library: the declarations below are the stable NCCL 2 ABI.
+#if __has_include(<rccl/rccl.h>) && !defined(PA_NO_RCCL_HEADER)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7, ncclFloat = 7, ncclBfloat16 = 9 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 #include <cstring>
 #include <mutex>

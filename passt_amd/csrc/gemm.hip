@@ -343,8 +343,11 @@ __device__ __forceinline__ auto tile_rsrc(const void* origin, int64_t bytes) {
 }
 static constexpr uint32_t V2_OOB = 0x80000000u;     // a lane offset no descriptor of < 2 GiB contains
 
-// rows of the blocked pre-activation buffer: whole 256-row tiles, so every pass of every tile height has its block
-__host__ __device__ __forceinline__ int64_t blocked_pre_rows(int M) { return ((int64_t)M + 255) / 256 * 256; }
+// rows of the blocked pre-activation buffer: whole multiples of 768 = lcm(256, 192, 128), so every 32-row pass of every
+// tile height (TM = 4 / 3 / 2) has its block inside the buffer -- rounding to 256 left the last passes of a 192-row tile
+// outside it for e.g. M = 474 * 7 (the block base rides in soffset, which the descriptor's range check does
+// not cover)
+__host__ __device__ __forceinline__ int64_t blocked_pre_rows(int M) { return ((int64_t)M + 767) / 768 * 768; }
 
 // Auxiliary rows of an item's epilogue (DGELU: pre-activation, RESID: residual): descriptor + the row vectors requested
 // ahead of their use.  The kernel calls issue() DURING the last K-tile of the item (the first rows come from HBM, not from
@@ -1946,6 +1949,22 @@ __global__ void convert_kernel(const float* __restrict__ in, T* __restrict__ out
     if (i < n) for (int64_t k = i; k < n && k < i + 4; ++k) out[k] = from_f32<T>(in[k]);
 }
 
+template <typename T>
+__global__ void convert_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    const bool vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    for (; i < n; i += stride) {
+        if (vec && i + 7 < n) {
+            float v[8];
+            load8<T>(in + i, v);
+            store8<float>(out + i, v);
+        } else {
+            for (int64_t k = i; k < n && k < i + 8; ++k) out[k] = to_f32<T>(in[k]);
+        }
+    }
+}
+
 // 64x64 tile transpose through LDS; out[c][r] = in[r][c], zero fill for r in [R, ldo).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, int R, int C, int ldi,
@@ -2130,6 +2149,16 @@ extern "C" int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, 
     const int blocks = (int)std::min<int64_t>(cdiv(n, 1024), 4096);
     if (dtype == PA_BF16) hipLaunchKernelGGL(convert_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
     else if (dtype == PA_F32) hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (float*)out, n);
+    else return PA_EINVAL;
+    return check_launch();
+}
+
+extern "C" int pa_convert_to_f32(const void* in, int dtype, float* out, int64_t n, void* stream) {
+    if (!in || !out || n < 0) return PA_EINVAL;
+    if (n == 0) return PA_OK;
+    const int blocks = (int)std::min<int64_t>(cdiv(n, 2048), 4096);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(convert_to_f32_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, n);
+    else if (dtype == PA_F32) hipLaunchKernelGGL(convert_to_f32_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)in, out, n);
     else return PA_EINVAL;
     return check_launch();
 }

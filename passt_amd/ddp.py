@@ -17,6 +17,8 @@ SURVEY.md 2.4) are not part of the flat buffer at all, so there is no unused-par
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def bucket_layout(named_sizes, depth):
     """named_sizes: [(name, numel)] in flat-buffer order.  Returns {bucket_id: (start, end)} with
@@ -58,7 +60,9 @@ class RcclAbiTransport:
             _lib.check(lib.pa_comm_unique_id(buf), "pa_comm_unique_id")
             box[0] = buf.raw
         if self.world > 1:
-            dist.broadcast_object_list(box, src=0, group=process_group)
+            # src is a GLOBAL rank: rank 0 of the (sub)group
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=process_group)
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             comm = C.c_void_p()
@@ -84,10 +88,16 @@ class RcclAbiTransport:
         return _Handle()
 
     def close(self):
-        if self.comm is not None:
+        if getattr(self, "comm", None) is not None:
             self.stream.synchronize()
             self._lib.check(self._lib.load().pa_comm_destroy(self.comm), "pa_comm_destroy")
             self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the process is going away with the communicator
+            pass
 
 
 class GradReducer:
@@ -107,6 +117,8 @@ class GradReducer:
         self.comm_dtype = comm_dtype
         self.abi = RcclAbiTransport(flat_grads.device, process_group) if (transport == "rccl_abi" and self.world > 1) else None
         self.pending = []
+        self._wires = {}
+        self.timing = None
 
     def _all_reduce(self, t):
         if self.abi is not None:
@@ -114,9 +126,10 @@ class GradReducer:
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def broadcast_(self, flat_params, src=0):
-        """Make every rank's parameters equal to rank ``src``'s (in place)."""
+        """Make every rank's parameters equal to those of rank ``src`` OF THE GROUP (in place)."""
         if self.world > 1:
-            dist.broadcast(flat_params, src, group=self.group)
+            gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+            dist.broadcast(flat_params, gsrc, group=self.group)
 
     def on_block_done(self, i):
         if self.world == 1:
@@ -126,27 +139,94 @@ class GradReducer:
             return
         # torch.distributed orders the collective after everything already enqueued on the current stream (the
         # kernels that produced this bucket) and runs it on the backend's communication stream
+        ev0 = None
+        if self.timing is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if self.comm_dtype == "fp32":
-            self.pending.append((self._all_reduce(self.flat[s:e]), None, s, e))
+            item = [self._all_reduce(self.flat[s:e]), None, s, e, i, ev0]
         else:
-            wire = self.flat[s:e].to(torch.bfloat16)
-            self.pending.append((self._all_reduce(wire), wire, s, e))
+            # one conversion kernel of the library each way (pa_convert_f32 / pa_convert_to_f32), not torch's cast + copy_
+            wire = self._wire(e - s)
+            if self.flat.is_cuda:
+                ops.convert_f32(self.flat[s:e], wire)
+            else:                       # the gloo logic tests of this class run on CPU tensors
+                wire.copy_(self.flat[s:e])
+            item = [self._all_reduce(wire), wire, s, e, i, ev0]
+        self.pending.append(item)
+
+    def _wire(self, n):
+        # wire buffers are reused from step to step (the reducer owns them: no allocator traffic inside the backward)
+        key = (len(self.pending), n)
+        buf = self._wires.get(key)
+        if buf is None:
+            buf = self._wires[key] = torch.empty(n, device=self.flat.device, dtype=torch.bfloat16)
+        return buf
+
+    def _finish(self, item):
+        w, wire, s, e, i, ev0 = item
+        ev1 = None
+        if self.timing is not None:
+            # time the current stream spends blocked on this bucket = what the step actually pays for it
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+        w.wait()                      # current stream waits for the communication stream
+        if self.timing is not None:
+            ev2 = torch.cuda.Event(enable_timing=True)
+            ev2.record()
+            self.timing.append((i, (e - s) * (4 if wire is None else 2), ev0, ev1, ev2))
+        if wire is not None:
+            if self.flat.is_cuda:
+                ops.convert_to_f32(wire, self.flat[s:e])
+            else:
+                self.flat[s:e].copy_(wire)
 
     def wait(self):
-        for w, wire, s, e in self.pending:
-            w.wait()                      # current stream waits for the communication stream
-            if wire is not None:
-                self.flat[s:e].copy_(wire)
-        self.pending = []
+        pending, self.pending = self.pending, []
+        for item in pending:
+            self._finish(item)
 
     def drain(self):
-        """Yield (start, end) of every launched bucket as soon as its all-reduce is ordered before the current stream."""
+        """Yield (start, end) of every launched bucket as soon as its all-reduce is ordered before the current stream.  If
+        the consumer stops early (an exception in the per-bucket optimizer), the remaining collectives are still waited
+        for: a half-drained reducer would leave all-reduces in flight on buffers the next step rewrites."""
         pending, self.pending = self.pending, []
-        for w, wire, s, e in pending:
-            w.wait()
-            if wire is not None:
-                self.flat[s:e].copy_(wire)
-            yield s, e
+        k = 0
+        try:
+            for k, item in enumerate(pending):
+                self._finish(item)
+                yield item[2], item[3]
+            k = len(pending)
+        finally:
+            for item in pending[k + 1:] if k < len(pending) else ():
+                self._finish(item)
+
+    def start_timing(self):
+        """bench.py, world > 1: record HIP events around every bucket (launch, first wait, released)."""
+        self.timing = []
+
+    def timing_summary(self):
+        """[{bucket, bytes, in_flight_ms (launch -> released: includes overlap with the backward), exposed_wait_ms (current
+        stream blocked), bus_GBps = 2(n-1)/n * bytes / in_flight}] of the buckets timed since start_timing(); call after a
+        device synchronize."""
+        out = []
+        n = self.world
+        for i, nbytes, ev0, ev1, ev2 in self.timing or []:
+            inflight, exposed = ev0.elapsed_time(ev2), ev1.elapsed_time(ev2)
+            out.append({"bucket": i, "bytes": nbytes, "in_flight_ms": round(inflight, 4), "exposed_wait_ms": round(exposed, 4),
+                        "bus_GBps": round(2.0 * (n - 1) / n * nbytes / max(inflight, 1e-6) / 1e6, 1)})
+        return out
+
+    def close(self):
+        if self.abi is not None:
+            self.abi.close()
+            self.abi = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def bucket_bytes(self):
         """{bucket id: bytes on the wire} in launch order (head, blocks depth-1 .. 0, patch embedding)."""

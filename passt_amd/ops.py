@@ -6,6 +6,7 @@ No fallback: a non-CUDA tensor or a missing library raises.
 """
 import ctypes as C
 import functools
+import threading
 import os
 
 import torch
@@ -18,15 +19,20 @@ TORCH_DTYPE = {PA_F32: torch.float32, PA_BF16: torch.bfloat16}
 PA_DTYPE = {torch.float32: PA_F32, torch.bfloat16: PA_BF16}
 
 
-_call_dev = None     # device of the tensors of the C-ABI call being assembled (set by _p, consumed by _stream)
+class _CallState(threading.local):
+    """Per-thread (the extension is entered from the trainer thread AND the autograd thread): the device of the
+    tensors of the C-ABI call being assembled -- set by _p(), consumed by _stream()."""
+    dev = None
+
+
+_call = _CallState()
 
 
 def _stream():
     """HIP stream the call is ordered on: the current stream OF THE DEVICE THE CALL'S TENSORS LIVE ON (not of
     torch.cuda.current_device(): a model on cuda:1 without set_device must not launch on cuda:0's stream).  Every
     wrapper passes its tensors through _p() first and _stream() last."""
-    global _call_dev
-    dev, _call_dev = _call_dev, None
+    dev, _call.dev = _call.dev, None
     return torch.cuda.current_stream(dev).cuda_stream
 
 
@@ -36,27 +42,65 @@ def _p(t, dtype=None, strided=False):
     only the last dimension must be dense, the leading dimension is passed separately) and the same device as the
     other tensors of the call.  The kernels reinterpret memory: a wrong dtype or a strided view would read garbage or
     out of bounds, so this raises instead."""
-    global _call_dev
     if t is None:
         return None
     if not t.is_cuda:
-        _call_dev = None
+        _call.dev = None
         raise _lib.PasstAmdError("passt_amd kernels need CUDA/HIP tensors (no CPU fallback)")
     if dtype is not None:
         want = TORCH_DTYPE.get(dtype, dtype)
         if t.dtype != want:
-            _call_dev = None
+            _call.dev = None
             raise _lib.PasstAmdError(f"expected a {want} tensor, got {t.dtype}")
     if not (t.is_contiguous() or (strided and t.dim() >= 1 and (t.shape[-1] <= 1 or t.stride(-1) == 1))):
-        _call_dev = None
+        _call.dev = None
         raise _lib.PasstAmdError(f"expected a {'row-dense' if strided else 'contiguous'} tensor, got strides {tuple(t.stride())} "
                                  f"for shape {tuple(t.shape)}")
-    if _call_dev is None:
-        _call_dev = t.device
-    elif t.device != _call_dev:
-        d0, _call_dev = _call_dev, None
+    if _call.dev is None:
+        _call.dev = t.device
+    elif t.device != _call.dev:
+        d0, _call.dev = _call.dev, None
         raise _lib.PasstAmdError(f"tensors of one kernel call live on different devices: {d0} and {t.device}")
     return t.data_ptr()
+
+
+class _PinnedRing:
+    """Small per-step host arrays (Patchout indices, mixup permutation / lambda) reach the device through page-locked
+    staging buffers: a copy from pageable memory is a synchronous staging copy that serialises against the communication
+    stream in a data-parallel run.  Four slots per (device, dtype, length) rotate; a slot is reused only after the event
+    behind its last copy has fired."""
+
+    def __init__(self, slots=4):
+        self.slots, self.rings = slots, {}
+
+    def upload(self, host, device):
+        host = torch.as_tensor(host)
+        key = (str(device), host.dtype, host.numel())
+        ring = self.rings.get(key)
+        if ring is None:
+            ring = self.rings[key] = {"i": 0, "buf": [torch.empty(host.numel(), dtype=host.dtype).pin_memory() for _ in range(self.slots)],
+                                      "ev": [None] * self.slots}
+        i = ring["i"]
+        ring["i"] = (i + 1) % self.slots
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        ring["buf"][i].copy_(host.reshape(-1))
+        out = ring["buf"][i].to(device, non_blocking=True).view(host.shape)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["ev"][i] = ev
+        return out
+
+
+_pinned = threading.local()
+
+
+def upload_small(host, device):
+    """host (numpy array / CPU tensor) -> device tensor through a pinned staging ring (asynchronous H2D)."""
+    ring = getattr(_pinned, "ring", None)
+    if ring is None:
+        ring = _pinned.ring = _PinnedRing()
+    return ring.upload(host, torch.device(device))
 
 
 # bench.py sets this to a dict to time every GEMM launch with HIP events on the launch stream:
@@ -109,6 +153,18 @@ def convert(x_f32, dtype):
     out = torch.empty(x_f32.shape, device=x_f32.device, dtype=TORCH_DTYPE[dtype])
     check(_lib.load().pa_convert_f32(_p(x_f32, torch.float32), _p(out), x_f32.numel(), dtype, _stream()), "pa_convert_f32")
     return out
+
+
+def convert_f32(x_f32, out_lp):
+    """out_lp[i] = (bf16 / f32) x_f32[i] into an existing tensor"""
+    check(_lib.load().pa_convert_f32(_p(x_f32, torch.float32), _p(out_lp), x_f32.numel(), PA_DTYPE[out_lp.dtype], _stream()),
+          "pa_convert_f32")
+
+
+def convert_to_f32(x_lp, out_f32):
+    """out_f32[i] = (float) x_lp[i]"""
+    check(_lib.load().pa_convert_to_f32(_p(x_lp), PA_DTYPE[x_lp.dtype], _p(out_f32, torch.float32), x_lp.numel(), _stream()),
+          "pa_convert_to_f32")
 
 
 def transpose(x, out_dtype, ldo=None, out=None):
@@ -235,9 +291,14 @@ class BlockedPre:
 
 
 @functools.lru_cache(maxsize=None)
+def _lib_blocked_pre_ok(M, N, K):
+    return bool(_lib.load().pa_gemm_blocked_pre_ok(M, N, K))
+
+
 def blocked_pre_ok(M, N, K):
-    return (not GEMM_TUNE and not os.environ.get("PASST_AMD_NO_BLOCKED_PRE")
-            and bool(_lib.load().pa_gemm_blocked_pre_ok(M, N, K)))
+    # only the library query is cached: GEMM_TUNE and the environment switch are read on every call (a
+    # result cached under a forced variant disabled -- or wrongly enabled -- the blocked path for the rest of the process)
+    return not GEMM_TUNE and not os.environ.get("PASST_AMD_NO_BLOCKED_PRE") and _lib_blocked_pre_ok(M, N, K)
 
 
 def linear_gelu(x_lp, W_lp, bias, dtype):
@@ -247,6 +308,9 @@ def linear_gelu(x_lp, W_lp, bias, dtype):
     act = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
     if dtype == PA_BF16 and blocked_pre_ok(M, N, x_lp.shape[1]):
         buf = torch.empty(_lib.load().pa_gemm_blocked_pre_elems(M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
+        # blocks of rows no wave tile of this GEMM writes: the GELU' epilogue of the last row tile adds and subtracts them
+        # for the fused bias sums, so they must be finite whatever tile height the two GEMMs resolve to
+        buf[(M + 31) // 32 * 32 * N:].zero_()
         gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=buf.view(-1, N), out_lp2=act, flags=GEMM_BLOCKED_PRE)
         return BlockedPre(buf, (M, N)), act
     pre = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
@@ -374,17 +438,18 @@ def wgrad_tn(dY, X, out_f32, dtype, accumulate=False, partial_ws=None, db=None):
     bpart = partial_ws[S * N * K:need] if db is not None else None
     a.colsum_ws = _p(bpart)
     lib = _lib.load()
-    if GEMM_PROFILE is None:
-        check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
-    else:
+    # the bracket covers the split-K reductions too: they are part of what a weight gradient costs
+    ev0 = ev1 = None
+    if GEMM_PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
-        ev1.record()
-        GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, 2.0 * N * K * Mtok))
+    check(lib.pa_gemm_tn(C.byref(a), _stream()), "pa_gemm_tn")
     check(lib.pa_reduce_partials(_p(part), S, N * K, _p(out_f32), int(accumulate), _stream()), "pa_reduce_partials")
     if db is not None:
         check(lib.pa_reduce_partials(_p(bpart), S, N, _p(db, torch.float32), int(accumulate), _stream()), "pa_reduce_partials")
+    if ev0 is not None:
+        ev1.record()
+        GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, 2.0 * N * K * Mtok))
     return partial_ws
 
 
@@ -432,15 +497,15 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
             rb.partial, rb.out, rb.n, rb.splits, rb.accumulate = _p(bpart), _p(db, torch.float32), N, S, int(acc)
         flops += 2.0 * N * K * Mtok
     lib = _lib.load()
-    if GEMM_PROFILE is None:
-        check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
-    else:
+    ev0 = ev1 = None
+    if GEMM_PROFILE is not None:        # the bracket covers the batched split-K reduction too
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
+    check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
+    check(lib.pa_reduce_partials_batched(red, nred, _stream()), "pa_reduce_partials_batched")
+    if ev0 is not None:
         ev1.record()
         GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, flops))
-    check(lib.pa_reduce_partials_batched(red, nred, _stream()), "pa_reduce_partials_batched")
     return partial_ws
 
 

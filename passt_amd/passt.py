@@ -246,8 +246,8 @@ def passt_forward(model, x, save):
         raise RuntimeError(f"patch grid has {F_dim} frequency rows but freq_new_pos_embed has {Fpe}")
     toff, T_eff, idx_t, idx_f, idx_u = draw_patchout(model, F_dim, T_dim)
     pf_np, pt_np = kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u)
-    pf = torch.from_numpy(pf_np).to(x.device, non_blocking=True)
-    pt = torch.from_numpy(pt_np).to(x.device, non_blocking=True)
+    pf = ops.upload_small(pf_np, x.device)         # page-locked staging: asynchronous H2D
+    pt = ops.upload_small(pt_np, x.device)
     D, H, depth = model.embed_dim, model.num_heads, len(model.blocks)
     Np = pf_np.size
     Ntok, M = Np + 2, B * (Np + 2)
@@ -697,9 +697,14 @@ class EnsembelerModel(nn.Module):
         return all_out, all_out
 
 
-def get_ensemble_model(arch_list=[]):
-    models_list = [get_model(arch=a, fstride=f, tstride=t, pretrained=False) for a, f, t in arch_list]
-    return EnsembelerModel(models_list)
+def get_ensemble_model(arch_list=[], *, pretrained=True):
+    """models/passt.py:1039-1045: every member through get_model() with ITS default pretrained=True, i.e. here through the
+    local checkpoint directory (PASST_AMD_CHECKPOINT_DIR/<arch>.pt; raises without one: no network).  `pretrained` is a
+    keyword-only extension for random-init members (tests, benchmarks)."""
+    models_list = [get_model(arch=a, fstride=f, tstride=t, pretrained=pretrained) for a, f, t in arch_list]
+    model = EnsembelerModel(models_list)
+    print(model)
+    return model
 
 
 try:  # the reference exposes these through a sacred/ba3l ingredient (models/passt.py:915-922)

@@ -61,6 +61,10 @@ class TrainStep:
         else:
             ops.sgd(self.flat_p[s:e], self.flat_g[s:e], self.lr)
 
+    def close(self):
+        """Release the reducer's communicator (C-ABI RCCL transport); torch.distributed groups belong to the caller."""
+        self.reducer.close()
+
     def set_lr_factor(self, factor):
         """Per-epoch LR schedule (ex_audioset.py:86-101): lr = base_lr * factor, e.g. from
         schedule.exp_warmup_linear_down(5, 50, 50, 0.01)(epoch)."""
@@ -84,8 +88,8 @@ class TrainStep:
             perm = torch.randperm(B)                                            # helpers/mixup.py:6
             lam = np.random.beta(self.mixup_alpha, self.mixup_alpha, B).astype(np.float32)
             lam = np.maximum(lam, 1.0 - lam)
-            perm_d = perm.to(torch.int32).to(x.device, non_blocking=True)
-            lam_d = torch.from_numpy(lam).to(x.device, non_blocking=True)
+            perm_d = ops.upload_small(perm.to(torch.int32), x.device)           # page-locked staging: asynchronous H2D
+            lam_d = ops.upload_small(lam, x.device)
             x = ops.mixup(x, perm_d, lam_d)
             if self.loss == "bce":
                 y = ops.mixup(y, perm_d, lam_d)

@@ -30,14 +30,19 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--overlap-wgrad", action="store_true")
     ap.add_argument("--optimizer", default="sgd")
+    ap.add_argument("--backend", default="gloo", help="gloo: every rank on cuda:0; nccl (= RCCL): rank r on cuda:r")
+    ap.add_argument("--transport", default="torch", help="torch | rccl_abi (pa_comm_* entry points; needs --backend nccl devices)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if (args.backend == "nccl" and world > 1) else 0)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     case = dict(G.CASES["model_small_train"], B=8, seed=333)
     cfg = case["cfg"]
     with warnings.catch_warnings():
@@ -61,7 +66,7 @@ def main():
         per = x.shape[0] // world
         xg, yg = xg[rank * per:(rank + 1) * per].contiguous(), yg[rank * per:(rank + 1) * per].contiguous()
     ts = TrainStep(net, None, lr=1e-3 if args.optimizer == "adamw" else 0.05, weight_decay=1e-2, use_mixup=False,
-                   comm_dtype=args.comm_dtype, optimizer=args.optimizer)
+                   comm_dtype=args.comm_dtype, optimizer=args.optimizer, transport=args.transport)
     init = ts.flat_p.clone()            # after the constructor's broadcast: rank 0's weights on every rank
     losses = []
     with warnings.catch_warnings():
@@ -84,6 +89,7 @@ def main():
         flags = [(True, losses)]
     if rank == 0:
         torch.save({"params": ts.flat_p.cpu(), "init": init.cpu(), "flags": flags, "world": world}, args.out)
+    ts.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -230,8 +230,8 @@ def test_host_side_queries_answer_without_a_gpu():
     assert lib.pa_gemm_tn_step_rows() == 48
     # headline MLP shape: role-split kernel -> blocked form available; rows padded to whole 256-row tiles
     assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3072, 768) == 1
-    assert lib.pa_gemm_blocked_pre_elems(64 * 474, 3072) == 30464 * 3072
-    assert lib.pa_gemm_blocked_pre_elems(256, 64) == 256 * 64
+    assert lib.pa_gemm_blocked_pre_elems(64 * 474, 3072) == 30720 * 3072      # rows rounded up to 768 = lcm of the tile heights
+    assert lib.pa_gemm_blocked_pre_elems(256, 64) == 768 * 64
     # compact rows of the last block (2 per clip) run on the generic kernel; N must be a multiple of 64
     assert lib.pa_gemm_blocked_pre_ok(128, 3072, 768) == 0
     assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3080, 768) == 0

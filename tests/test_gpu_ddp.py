@@ -77,6 +77,34 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(tmp_path, variant
         assert e < (1e-4 if variant != "bf16_wire" else 1e-2), e
 
 
+def _check_against_single_process(dp, ref, variant):
+    assert all(same for same, _ in dp["flags"])
+    assert torch.equal(dp["init"], ref["init"])
+    world = dp["world"]
+    for step, full in enumerate(ref["flags"][0][1]):
+        parts = [l[step] for _, l in dp["flags"]]
+        assert abs(sum(parts) / world - full) < (5e-6 if "bf16" not in variant else 5e-4), (step, parts, full)
+    d_dp, d_ref = (dp["params"] - dp["init"]).double(), (ref["params"] - ref["init"]).double()
+    e = float((d_dp - d_ref).abs().max() / d_ref.abs().max())
+    assert e < (1e-4 if "bf16" not in variant else 1e-2), e
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on the first multi-GPU box")
+@pytest.mark.parametrize("transport", ["torch", "rccl_abi"])
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_ranks_over_rccl_equal_one_process(tmp_path, transport, wire):
+    """The same comparison over the REAL wire: backend nccl (= RCCL over xGMI), one device per rank, through
+    torch.distributed and through the library's own pa_comm_* entry points; 2 ranks and -- when the box has them -- 4 / 8
+    (global batch 8).  Skipped on a single-GPU box, self-verifying on the first node that has more."""
+    ref = _run(str(tmp_path / "ref.pt"), 1)
+    worlds = [w for w in (2, 4, 8) if w <= torch.cuda.device_count()]
+    for world in worlds:
+        extra = ("--backend", "nccl", "--transport", transport) + (("--comm-dtype", "bf16") if wire == "bf16" else ())
+        dp = _run(str(tmp_path / f"dp{world}.pt"), world, extra)
+        assert dp["world"] == world
+        _check_against_single_process(dp, ref, wire)
+
+
 def test_rccl_abi_transport_single_rank():
     """The C-ABI collective entry (pa_comm_init / pa_allreduce_bucket, RCCL loaded by the library) on the one GPU a test
     box has: a world of 1 is the identity, for both wire types, ordered on the transport's own stream; a second bucket

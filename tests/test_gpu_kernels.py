@@ -653,8 +653,32 @@ def test_persistent_gemm_edge_shapes(tune, M, N, K):
         ops.GEMM_TUNE = old
 
 
+def test_blocked_pre_buffer_holds_every_pass_of_every_tile_height():
+    """pa_gemm_blocked_pre_elems covers whole 128-, 192- and 256-row tiles (with rows rounded to 256 the last
+    32-row passes of a 192-row tile at e.g. M = 474 * 7 were written past the buffer), and the forward GELU GEMM leaves
+    a canary behind the buffer untouched."""
+    lib = ops._lib.load()
+    for M in (474 * 7, 474 * 14, 474 * 41, 353 * 18, 790 * 11, 1000, 1, 768):
+        rows = lib.pa_gemm_blocked_pre_elems(M, 64) // 64
+        for hgt in (128, 192, 256):
+            assert rows >= (M + hgt - 1) // hgt * hgt, (M, hgt, rows)
+    M, N, K = 474 * 7, 3072, 768
+    if not ops.blocked_pre_ok(M, N, K):
+        pytest.skip("the library runs this shape on a kernel without the blocked form")
+    n = lib.pa_gemm_blocked_pre_elems(M, N)
+    big = torch.empty(n + (1 << 16), device=DEV, dtype=torch.bfloat16)
+    big[n:] = 123.0
+    x = rnd(M, K, seed=31).to(torch.bfloat16).to(DEV)
+    W = (rnd(N, K, seed=32) * 0.05).to(torch.bfloat16).to(DEV)
+    act = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(x, W, PA_BF16, EPI_GELU, bias=rnd(N, seed=33).to(DEV), out_lp=big[:n].view(-1, N), out_lp2=act, flags=ops.GEMM_BLOCKED_PRE)
+    torch.cuda.synchronize()
+    assert bool((big[n:] == 123.0).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(2304, 3072, 768), (1999, 3072, 768), (30336, 3072, 768), (777, 1024, 256), (4000, 4096, 1024),
-                                   (5003, 3072, 768), (8200, 1536, 768), (25280, 4096, 1024), (12345, 3136, 832)])
+                                   (5003, 3072, 768), (8200, 1536, 768), (25280, 4096, 1024), (12345, 3136, 832), (474 * 7, 3072, 768),
+                                   (353 * 18, 3072, 768)])
 def test_blocked_pre_activation_equals_row_major(M, N, K):
     """PA_GEMM_BLOCKED_PRE: fc1 + GELU writes the pre-activation in the blocked accumulator-order layout and the GELU'
     epilogue of the input-gradient GEMM reads it back: activation, d_pre and the fused fc1.bias column sums are

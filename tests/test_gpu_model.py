@@ -350,9 +350,18 @@ def test_ensemble_and_other_strides_eval():
     """get_ensemble_model (models/passt.py:1021-1045): mean of the member logits; members with stride 10 and stride 14
     (different patch grids: 12x99 and 9x71) each against the oracle."""
     archs = [("passt_s_swa_p16_128_ap476", 10, 10), ("passt_s_swa_p16_s14_128_ap471", 14, 14)]
-    with warnings.catch_warnings():
+    import contextlib, io
+    # the reference's default (pretrained=True) goes through the local checkpoint directory and must say so without one
+    old = os.environ.pop("PASST_AMD_CHECKPOINT_DIR", None)
+    try:
+        with pytest.raises(RuntimeError, match="PASST_AMD_CHECKPOINT_DIR"):
+            passt_amd.get_ensemble_model(archs)
+    finally:
+        if old is not None:
+            os.environ["PASST_AMD_CHECKPOINT_DIR"] = old
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
         warnings.simplefilter("ignore")
-        ens = passt_amd.get_ensemble_model(archs)
+        ens = passt_amd.get_ensemble_model(archs, pretrained=False)
     x = torch.from_numpy(detgen.uniform(61, "x", (2, 1, 128, 998), -1.5, 1.5))
     outs = []
     for i, (m, (_, fs, ts)) in enumerate(zip(ens.models, archs)):

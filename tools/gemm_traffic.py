@@ -3,9 +3,18 @@
 (FETCH_SIZE and WRITE_SIZE must be collected separately: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 gfx950 correction: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> x2 (validated here on
 ln_fwd_kernel: 93.2 MB read -> 45.5e3 KB reported, and mel_frontend_kernel).  Units: KB."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha16(rel):
+    with open(os.path.join(ROOT, rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def per_kernel(db, counter):
@@ -32,7 +41,8 @@ for name in fetch:
         tot_f += 2 * sum(f)
         tot_w += sum(w) * len(f) / max(1, len(w))
         n += len(f)
-summary = {"kernel_family": "pa::gemm_nt_* + pa::gemm_tn_* (bf16)", "launches": n,
+# bench.py only reports this number while the kernel source it was measured on is unchanged (committed_traffic())
+summary = {"kernel_family": "pa::gemm_nt_* + pa::gemm_tn_* (bf16)", "launches": n, "source_sha16": {"gemm.hip": sha16("passt_amd/csrc/gemm.hip")},
            "hbm_bytes_per_launch": round((tot_f + tot_w) * 1e3 / max(1, n)),
            "read_bytes_per_launch": round(tot_f * 1e3 / max(1, n)), "write_bytes_per_launch": round(tot_w * 1e3 / max(1, n)),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1`; "
@@ -47,7 +57,8 @@ if len(sys.argv) > 3:
         f, w = mf[0], mw[0]
         rd, wr = 2 * sum(f) / len(f) * 1e3, sum(w) / len(w) * 1e3
         with open(sys.argv[3], "w") as fh:
-            json.dump({"kernel": "pa::mel_frontend_kernel", "launches": len(f), "read_bytes_per_launch": round(rd),
+            json.dump({"kernel": "pa::mel_frontend_kernel", "launches": len(f), "source_sha16": {"mel.hip": sha16("passt_amd/csrc/mel.hip")},
+                       "read_bytes_per_launch": round(rd),
                        "write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                        "algorithmic_bytes_per_launch": 64 * (320000 + 128 * 1000) * 4,
                        "method": summary["method"]}, fh, indent=1)
