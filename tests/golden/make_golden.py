@@ -48,6 +48,10 @@ BIG_CASES = {
     # passt_s_f128_20sec_p16_s10_ap474 / passt_s_f128_30sec_p16_s10_ap473 (models/passt.py:990-1003): N = 2390 / 3590
     "model_passt_s_20s_eval": dict(cfg=O.make_cfg(img_size=(128, 2000)), B=1, T=2000, training=False, seed=17),
     "model_passt_s_30s_eval": dict(cfg=O.make_cfg(img_size=(128, 3000)), B=1, T=3000, training=False, seed=18),
+    # r03: BASELINE config #5 at real depth -- ESC-50 fine-tune (ex_esc50.py:60): n_classes=50, 5 s clips (500 frames into a
+    # 998-frame model: random time-pos-embed offset), s_patchout_t=10, s_patchout_f=3 => 353 tokens
+    "model_esc50_train_full": dict(cfg=O.make_cfg(num_classes=50, s_patchout_t=10, s_patchout_f=3), B=2, T=500, training=True,
+                                   seed=19, torch_seed=555, compact=True),
 }
 FRONTEND_CASES = {
     "frontend_eval": dict(B=2, L=32000, training=False, seed=21,
@@ -216,9 +220,10 @@ def gen_rng_kat():
 if __name__ == "__main__":
     assert ref_import.reference_available(), "needs /root/reference"
     torch.set_num_threads(min(32, os.cpu_count()))
-    if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the full-size cases (minutes of CPU time)
+    if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the full-size cases (minutes of CPU time); big <name>: one of them
         for n, c in BIG_CASES.items():
-            gen_model_case(n, c)
+            if len(sys.argv) < 3 or n in sys.argv[2:]:
+                gen_model_case(n, c)
         sys.exit(0)
     for n, c in CASES.items():
         gen_model_case(n, c)

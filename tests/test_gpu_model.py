@@ -273,6 +273,73 @@ def test_train_step_driver_matches_autograd_path():
         assert rel(p2.detach().cpu(), p1.detach().cpu()) < 2e-4, k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_step_two_steps_at_bench_shape_vs_oracle(precision):
+    """The headline step itself -- spectrogram mixup + PaSST 768/12/12 at 474 tokens (s_patchout_t=40, f=4: prefix-only tail,
+    batched weight gradients, flat buffers) + BCE + fused AdamW -- two consecutive steps of passt_amd.train.TrainStep at
+    B = 4 against the oracle driven by torch.optim.AdamW with the same RNG stream (helpers/mixup.py:5-12 draw order, then
+    the Patchout draws).  Losses of BOTH steps (the second sees the first update) and the parameter updates.  AdamW's
+    first steps are lr * sign(g): an entry whose gradient is smaller than its error flips, so the updates are judged by
+    direction (cosine per tensor) and, in fp32, by relative L2."""
+    from passt_amd.train import TrainStep
+    case = dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=4, T=998, seed=77)
+    cfg, B = case["cfg"], case["B"]
+    x, y = G.model_inputs(case)
+    lr, wd, alpha = 1e-3, 1e-2, 0.3
+    # --- oracle
+    sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]), requires_grad=True)
+    init = {k: v.detach().clone() for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for k, v in sd.items() if not k.startswith("head_dist.")], lr=lr, weight_decay=wd)
+    ref_losses = []
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for step in range(2):
+        torch.manual_seed(4000 + step)
+        np.random.seed(4000 + step)
+        rn, lam = O.my_mixup(B, alpha)
+        xm, ym = O.mixup_apply(torch.from_numpy(x), torch.from_numpy(y), rn, lam)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lo, _ = O.passt_forward(sd, xm, cfg, training=True)
+        loss = O.bce_loss(lo, ym)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+    # --- TrainStep on the HIP kernels
+    net = build(case, precision).train()
+    ts = TrainStep(net, None, lr=lr, weight_decay=wd, mixup_alpha=alpha, use_mixup=True)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(2):
+            torch.manual_seed(4000 + step)
+            np.random.seed(4000 + step)
+            losses.append(float(ts.step(xg, yg).item()))
+    ltol = 2e-5 if precision == "fp32" else 3e-3
+    assert all(abs(a - b) < ltol for a, b in zip(losses, ref_losses)), (losses, ref_losses)
+    worst_cos, worst_l2 = 1.0, 0.0
+    for name, p in ts.named:
+        d = (p.detach().double().cpu() - init[name].double()).reshape(-1)
+        dr = (sd[name].detach().double() - init[name].double()).reshape(-1)
+        if name.endswith("attn.qkv.bias"):
+            # the key bias shifts every score of a row equally: its true gradient is 0 and AdamW steps along the sign of
+            # pure round-off there -- leave the K third out of the direction check
+            third = d.numel() // 3
+            keep = torch.cat([torch.arange(0, third), torch.arange(2 * third, 3 * third)])
+            d, dr = d[keep], dr[keep]
+        if float(dr.norm()) == 0.0:
+            continue
+        cos = float((d @ dr) / (d.norm() * dr.norm() + 1e-300))
+        l2 = float((d - dr).norm() / dr.norm())
+        worst_cos, worst_l2 = min(worst_cos, cos), max(worst_l2, l2)
+        assert cos > (0.999 if precision == "fp32" else 0.9), (name, cos)
+        if precision == "fp32":
+            assert l2 < 3e-2, (name, l2)
+    record(f"train_step_vs_oracle[{precision}]", loss0=abs(losses[0] - ref_losses[0]), loss1=abs(losses[1] - ref_losses[1]),
+           worst_update_cosine=worst_cos, worst_update_rel_l2=worst_l2)
+
+
 def test_swa_matches_reference_update_rule():
     """schedule.SWA (one fused kernel on the flat buffer) == helpers/swa_callback.py:246-268 applied per tensor
     (restated here: avg = p for the first snapshot, then avg + (p - avg) / (n + 1)); copy_to() loads a deepcopy."""

@@ -205,3 +205,36 @@ def test_wave_oracle_pinned_to_reference_outputs():
     eye = np.eye(len(c["lens"]), dtype=np.float32)
     tgt = np.stack([w[b] * eye[b] + (1 - w[b]) * eye[max(c["partner"][b], 0)] for b in range(len(w))])
     assert np.abs(tgt - g["target"]).max() < 1e-7
+
+
+def test_mask_along_axis_published_contract():
+    """torchaudio.functional.mask_along_axis is an un-vendored dependency with no copy on this machine (parity UNPINNED for
+    the RNG draw order).  What CAN be pinned offline is torchaudio's published contract for the transforms the
+    reference builds (FrequencyMasking(freqm) / TimeMasking(timem), models/preprocess.py:50,54): ONE contiguous band per
+    call, shared by the whole batch, of width uniformly drawn from [0, mask_param) and placed uniformly inside the axis,
+    filled with mask_value, everything else untouched; mask_param larger than the axis is clamped (iid_masks=True path)."""
+    torch.manual_seed(7)
+    x = torch.randn(3, 128, 200) + 10.0                      # never equal to the fill value
+    widths_f, widths_t, starts_t = [], [], []
+    for axis, param, size, widths in ((1, 48, 128, widths_f), (2, 80, 200, widths_t)):
+        for _ in range(400):
+            y = O.mask_along_axis(x, param, 0.0, axis)
+            hit = (y == 0.0)
+            assert torch.equal(y[~hit], x[~hit])
+            line = hit.any(dim=2 if axis == 1 else 1)        # (B, size): which indices of the axis are masked
+            assert torch.equal(line[0], line[1]) and torch.equal(line[0], line[2])          # one mask for the batch
+            full = hit.all(dim=2 if axis == 1 else 1)
+            assert torch.equal(full, line)                   # whole rows / columns
+            idx = line[0].nonzero().reshape(-1)
+            w = int(idx.numel())
+            assert w < param and (w == 0 or int(idx[-1] - idx[0]) == w - 1)              # contiguous, width in [0, param)
+            widths.append(w)
+            if axis == 2 and w:
+                starts_t.append(int(idx[0]))
+    # uniform width: mean (param - 1) / 2, every width reachable; starts spread over the axis
+    assert abs(np.mean(widths_f) - 23.5) < 2.5 and abs(np.mean(widths_t) - 39.5) < 4.0
+    assert min(widths_f) == 0 and max(widths_f) >= 44 and max(widths_t) >= 72
+    assert min(starts_t) < 15 and max(starts_t) > 120
+    # clamp: mask_param beyond the axis length
+    y = O.mask_along_axis(x[:, :, :30], 192, 0.0, 2)
+    assert int((y == 0.0).any(dim=1)[0].sum()) < 30
