@@ -205,6 +205,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry run of the N > 1 code path on a box with ONE GPU (tests/test_gpu_ddp.py::test_bench_multi_rank_dry_run): every rank
+    # on device 0 over gloo.  The line it prints says so (config.parallelism) and is not a measurement of anything.
+    dry = os.environ.get("PASST_AMD_BENCH_DRY_GLOO") == "1"
+    if dry:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -214,7 +219,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import passt_amd
     from passt_amd import ops
@@ -321,7 +329,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
-                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
                        "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
             "algorithmic_gflop_per_clip": round(gflop_clip, 2),

@@ -121,3 +121,30 @@ def test_rccl_abi_transport_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(a, a0) and torch.equal(b, b0)
     tr.close()
+
+
+def test_bench_multi_rank_dry_run():
+    """bench.py's N > 1 path end to end -- rank / world from the environment, barrier + max-over-ranks timing, the
+    reducer's bucket callbacks, the MEASURED all-reduce object (HIP events per bucket), one JSON line from rank 0 -- on the
+    one GPU a test box has: two ranks on device 0 over gloo (PASST_AMD_BENCH_DRY_GLOO=1).  The 8-GPU run is the driver's;
+    this is what keeps it from tripping over an untested code path."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PASST_AMD_BENCH_DRY_GLOO="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        outs.append((p.returncode, o.decode(), e.decode()[-1500:]))
+    assert all(rc == 0 for rc, _, _ in outs), outs
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][1].splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and "DRY RUN" in d["config"]["parallelism"]
+    ar = d["allreduce_measured"]
+    assert len(ar["buckets"]) == 14 and ar["bytes_per_step"] > 300e6          # head + 12 blocks + patch embedding, f32
+    assert all(b["in_flight_ms"] > 0 and b["exposed_wait_ms"] >= 0 for b in ar["buckets"])
