@@ -10,8 +10,13 @@
 //   :78     log(mel + 1e-5), :80-82 SpecAugment masks, :84 (x+4.5)/5 -> epilogue
 // HBM traffic = read the waveform once (+6% halo) and write the mel tile once.
 //
-// Workgroup = 4 waves = 32 consecutive frames of one clip (8 frames per wave); the 32-frame output
-// tile is transposed through LDS so every mel row is written as 128 contiguous bytes.
+// Workgroup = 4 waves = FR_PER_WG consecutive frames of one clip; the output tile is transposed through LDS so every
+// mel row leaves as FR_PER_WG * 4 contiguous bytes.
+// r03: 16 frames per workgroup instead of 32.  The kernel is latency bound (dependent butterfly chains, two LDS
+// exchanges per frame, ~11 cycles per instruction at two waves per SIMD); 51 KiB of LDS fit THREE workgroups per CU:
+// 133 -> 108 us at B = 64 (8 frames: 106 us but 32-byte output rows).  A persistent variant (workgroups walking the tiles,
+// geometry / twiddles set up once, next tile's span prefetched into registers) measured slower, 128-130 us: the
+// prefetch registers cost the third wave (201 VGPRs) or spill, and static tile ranges balance worse than the dispatcher.
 //
 // r02 (profiles/r02_mel_variants.txt): the FFT is NOT what the kernel waits for.  With 8 waves and ~100 KiB of LDS per
 // workgroup only one workgroup fitted a CU, and each one spent ~3/4 of its life in its un-overlapped prologue (a
@@ -28,7 +33,10 @@ namespace pa {
 
 static constexpr int NFFT = 1024;
 static constexpr int NC = 512;            // complex points
-static constexpr int FR_PER_WG = 32;
+#ifndef PA_MEL_FRAMES
+#define PA_MEL_FRAMES 16
+#endif
+static constexpr int FR_PER_WG = PA_MEL_FRAMES;   // frames per workgroup
 static constexpr int MEL_WAVES = 4;
 static constexpr int XROW1 = 68;          // exchange-1 row stride (complex) : conflict-free reads
 static constexpr int XROW2 = 72;          // exchange-2 row stride (complex)

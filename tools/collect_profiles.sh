@@ -29,7 +29,7 @@ python $R/tools/gemm_traffic.py "$F" "$W" "$O/mel_traffic.json" > "$O/gemm_traff
 python $R/tools/rocpd_stats.py "$F" --top 25 > "$O/pmc_fetch.txt" 2>&1
 python $R/tools/rocpd_stats.py "$W" --top 25 > "$O/pmc_write.txt" 2>&1
 
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pm -o m -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$O/pm.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace -d /tmp/pm -o m -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$O/pm.log" 2>&1
 python $R/tools/rocpd_stats.py "$(find /tmp/pm -name '*.db' | head -1)" --top 16 > "$O/pmc_mfma.txt" 2>&1
 
 cd "$R"
