@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 2   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale* */
+#define PA_ABI_VERSION 3   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
+                            * 3: pa_gemm_nt_splitk* */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -187,6 +188,15 @@ int pa_gemm_blocked_pre_ok(int M, int N, int K);
 int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
+/* The same product for problems too small to fill the chip (few output tiles, long K: the [M][768] outputs of fc2 / the
+ * fc1 and qkv input gradients at ESC-50 batch sizes, ex_esc50.py:40; the prefix-only tail of the last block): K is cut into
+ * pa_gemm_nt_splitk_plan(...) slices whose f32 partial tiles go to the caller's workspace `ws` (at least
+ * pa_gemm_nt_splitk_ws_floats(...) floats) and one elementwise pass applies the epilogue.  PA_EPI_STORE / PA_EPI_RESID
+ * (row_mod == 0), bf16, tune == 0; whenever the plan is 1 slice -- or ws is NULL / too small -- this IS pa_gemm_nt(a).
+ * Results differ from pa_gemm_nt only in the order of the f32 partial sums. */
+int pa_gemm_nt_splitk_plan(int M, int N, int K, int epilogue, int dtype);
+int64_t pa_gemm_nt_splitk_ws_floats(int M, int N, int K, int epilogue, int dtype);
+int pa_gemm_nt_splitk(const pa_gemm_args* a, float* ws, int64_t ws_floats, void* stream);
 /* Weight gradient  C[a->M][a->N] = sum_{m < a->K} A[m][a->M]^T B[m][a->N]  (A = dY, B = X, both row-major
  * [tokens][features] read IN PLACE, no transposed copies).  epilogue must be PA_EPI_PARTIAL: split-K over
  * the token axis, out_f32[split_k][M][N] partial slabs, finished by pa_reduce_partials (deterministic).

@@ -60,6 +60,9 @@ SIGNATURES = {
     "pa_gemm_blocked_pre_ok": (i32, [i32, i32, i32]),
     "pa_gemm_blocked_pre_elems": (i64, [i32, i32]),
     "pa_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "pa_gemm_nt_splitk_plan": (i32, [i32, i32, i32, i32, i32]),
+    "pa_gemm_nt_splitk_ws_floats": (i64, [i32, i32, i32, i32, i32]),
+    "pa_gemm_nt_splitk": (i32, [C.POINTER(GemmArgs), vp, i64, vp]),
     "pa_gemm_tn": (i32, [C.POINTER(GemmArgs), vp]),
     "pa_gemm_tn_batched": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "pa_gemm_tn_step_rows": (i32, []),
@@ -118,7 +121,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype, fn.argtypes = res, args
-    if lib.pa_abi_version() != 2:      # include/passt_amd.h PA_ABI_VERSION
+    if lib.pa_abi_version() != 3:      # include/passt_amd.h PA_ABI_VERSION
         raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -1422,9 +1422,11 @@ static_assert(TN_ROWS % 16 == 0 && TN_ROWS * 512 % (8 * 1024) == 0, "whole 16-to
 // per block) by +1/8 MFMA work in 1/12 of the work items.
 // (CSUM is a wave-uniform run-time flag, not a template parameter: a second copy of the item would double a kernel that
 // is already ~50 KB of code, and the instruction cache is 64 KB per two CUs.)
-__device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int split,
-                                                     const int steps_per_split) {
-    const bool CSUM = a.colsum_ws != nullptr && tile_id % tiles_n == 0;
+// One work item: tile `tile_id` of problem `a` over the token steps [st_begin, st_begin + nsteps); the f32 partial tile goes
+// to out[m * ldo + n] (m, n = coordinates in the whole gradient matrix), the column sums of dY (CSUM) to cs_out[m].
+__device__ __forceinline__ void gemm_tn_stagger_range(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int st_begin,
+                                                      const int nsteps, float* out, const int ldo, float* cs_out) {
+    const bool CSUM = cs_out != nullptr && tile_id % tiles_n == 0;
     constexpr int TM = 4, WN = 4, MROWS = TN_ROWS, NPH = MROWS / 16;
     constexpr int OP_BYTES = TN_OP_BYTES, STAGE_BYTES = TN_STAGE_BYTES;
     constexpr int PER = OP_BYTES / 1024 / 8;               // LDS-DMA pieces per wave, operand and stage: 3
@@ -1436,9 +1438,6 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
     const int bid = tile_id;
     const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;     // dY columns / X columns of this tile
     const int Mtok = a.K;
-    const int steps_total = (Mtok + MROWS - 1) / MROWS;
-    const int st_begin = split * steps_per_split;
-    const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
 
     // this wave's PER + PER LDS-DMA pieces per stage: piece q = wave*PER+i covers tile rows 2q, 2q+1 (512 B each).
     // Source address = uniform base of the stage (SGPRs, advanced by MROWS token rows per stage) + a per-lane
@@ -1806,10 +1805,15 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
         for (int i = tid; i < 2 * PROBE_SLOTS; i += 512)
             g_probe_buf[(size_t)blockIdx.x * 2 * PROBE_SLOTS + i] = ((unsigned long long*)(smem + TN_LDS))[i];
 #endif
-    gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(a, acc, nullptr, m0, n0, split, wr, wc, lane);
+    {
+        pa_gemm_args e = a;
+        e.out_f32 = out;
+        e.ldo32 = ldo;
+        gemm_epilogue_f32_direct<PA_EPI_PARTIAL, TM>(e, acc, nullptr, m0, n0, 0, wr, wc, lane);
+    }
     if (CSUM) {                        // every column of the 32x32 block holds the same sums: lanes 0 and 32 write them
         if ((lane & 31) == 0) {
-            float* dst = a.colsum_ws + (int64_t)split * a.M;
+            float* dst = cs_out;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 128 + wc * 32 + acc_row(r, lane);
@@ -1817,6 +1821,16 @@ __device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, cons
             }
         }
     }
+}
+
+// split-K form: slice `split` of `steps_per_split` token steps, partial slab out_f32[split][M][ldo32]
+__device__ __forceinline__ void gemm_tn_stagger_item(const pa_gemm_args& a, const int tiles_n, const int tile_id, const int split,
+                                                     const int steps_per_split) {
+    const int steps_total = (a.K + TN_ROWS - 1) / TN_ROWS;
+    const int st_begin = split * steps_per_split;
+    const int nsteps = min(steps_total, st_begin + steps_per_split) - st_begin;
+    gemm_tn_stagger_range(a, tiles_n, tile_id, st_begin, nsteps, a.out_f32 + (int64_t)split * a.M * a.ldo32, a.ldo32,
+                          a.colsum_ws ? a.colsum_ws + (int64_t)split * a.M : nullptr);
 }
 
 __global__ __launch_bounds__(512) void gemm_tn_stagger_kernel(const pa_gemm_args a, const int tiles_n, const int nwg,
@@ -1859,6 +1873,11 @@ __global__ __launch_bounds__(512) void gemm_tn_stagger_batched_kernel(const TnBa
     gemm_tn_stagger_item(b.a[p], b.tiles_n[p], t, split, b.per[p]);
 }
 
+// (r03: a stream-K form of the batched launch -- ONE sequence of tiles x token steps cut into 256 equal contiguous runs,
+// one per CU, 364 partial tiles instead of 756, no round quantisation -- measured 504 us + 23 us fix-up against 382 + 36:
+// in tile-major runs the CUs working at the same time sit at different token offsets, nobody shares a dY / X panel stage and
+// every tile streams both panels from HBM, 3.35 GB per launch instead of 0.96.  The slice-major split-K order is what keeps
+// this kernel off the HBM roofline; profiles/r03_streamk_experiment.txt.)
 static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
 #ifdef PA_PROBE
     constexpr int LDS = TN_LDS + 2 * PROBE_SLOTS * 8;
@@ -2117,6 +2136,34 @@ __global__ void gather_rows_kernel(const char* __restrict__ in, const int32_t* _
     }
 }
 
+// Finish of a split-K NT GEMM (pa_gemm_nt_splitk): out = epilogue(sum_z ws[z][m][n]) for the two epilogues whose output is
+// a plain function of the accumulator -- STORE: (acc + bias) * colscale -> bf16, RESID: acc + bias + resid -> f32.
+// One 16-byte vector of 4 columns per thread and step; N % 8 == 0.
+template <int EPI>
+__global__ void nt_splitk_finish_kernel(pa_gemm_args a, const float* __restrict__ ws, int splits) {
+    const int nv = a.N >> 2;
+    const int64_t total = (int64_t)a.M * nv, slab = (int64_t)a.M * a.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv), n = (int)(i - (int64_t)m * nv) * 4;
+        const float* src = ws + (int64_t)m * a.N + n;
+        f32x4 v = *(const f32x4*)src;
+        for (int z = 1; z < splits; ++z) v += *(const f32x4*)(src + z * slab);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b = *(const f32x4*)(a.bias + n);
+        if constexpr (EPI == PA_EPI_STORE) {
+            const float cs = n < a.colscale_n ? a.colscale : 1.f;
+            uint32_t o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)        // the same multiply-add as the fused epilogue: acc * cs + bias * cs
+                o[e] = cvt_pk_bf16(fmaf(v[2 * e], cs, b[2 * e] * cs), fmaf(v[2 * e + 1], cs, b[2 * e + 1] * cs));
+            *(uint2*)((bf16*)a.out_lp + (int64_t)m * a.ldolp + n) = uint2{o[0], o[1]};
+        } else {
+            const f32x4 r = *(const f32x4*)(a.resid + (int64_t)m * a.ldr + n);
+            *(f32x4*)(a.out_f32 + (int64_t)m * a.ldo32 + n) = (v + b) + r;
+        }
+    }
+}
+
 }  // namespace pa
 
 using namespace pa;
@@ -2141,6 +2188,59 @@ extern "C" int pa_gemm_nt(const pa_gemm_args* a, void* stream) {
     if (a->dtype == PA_BF16) return dispatch_gemm<bf16>(*a, st);
     if (a->dtype == PA_F32) return dispatch_gemm<float>(*a, st);
     return PA_EINVAL;
+}
+
+// ---- split-K for NT problems that leave most of the chip idle -------------------------------------------------------
+// A [M][768] output of 128x256 tiles is 3 tiles per 128 rows: ESC-50 fine-tuning at batch 12 (M = 4236) has 102 tiles for
+// 256 CUs, the prefix-only tail of the last block (M = 2 B) has 3 -- and K = 2304 / 3072 of serial work in each.  The plan
+// cuts K into `splits` slices so that tiles x splits fills the CUs (role-split kernel, PA_EPI_PARTIAL slabs in the caller's
+// workspace) and one elementwise kernel applies the epilogue.  Only STORE / RESID (without the patch-embed row remap), bf16.
+extern "C" int pa_gemm_nt_splitk_plan(int M, int N, int K, int epilogue, int dtype) {
+    if (dtype != PA_BF16 || (epilogue != PA_EPI_STORE && epilogue != PA_EPI_RESID)) return 1;
+    if (M <= 0 || N <= 0 || K <= 0 || (K * 2) % KB || N % 8) return 1;
+    static const int off = [] { const char* e = getenv("PA_NT_SPLITK"); return e && atoi(e) == 0 ? 1 : 0; }();
+    if (off) return 1;
+    const int v = pick_nt_variant(M, N, K);
+    if (v != 6 && v != 7 && v != 8) return 1;
+    const int tm = v == 6 ? 4 : (v == 7 ? 3 : 2);
+    const int64_t tiles = cdiv(M, 64 * tm) * cdiv(N, 256);
+    const int ksteps = K * 2 / KB;
+    if (tiles > 128 || ksteps < 16) return 1;
+    // at least 6 K-tiles per slice (prologue and slab write stay a small part of an item), at most 16 slices
+    const int s = (int)std::min<int64_t>(std::min<int64_t>(256 / tiles, ksteps / 6), 16);
+    return s >= 2 ? s : 1;
+}
+
+extern "C" int64_t pa_gemm_nt_splitk_ws_floats(int M, int N, int K, int epilogue, int dtype) {
+    const int s = pa_gemm_nt_splitk_plan(M, N, K, epilogue, dtype);
+    return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+extern "C" int pa_gemm_nt_splitk(const pa_gemm_args* a, float* ws, int64_t ws_floats, void* stream) {
+    if (!a) return PA_EINVAL;
+    const int s = (a->row_mod > 0 || a->split_k > 1 || a->tune) ? 1 : pa_gemm_nt_splitk_plan(a->M, a->N, a->K, a->epilogue, a->dtype);
+    if (s <= 1 || !ws || ws_floats < (int64_t)s * a->M * a->N) return pa_gemm_nt(a, stream);
+    if (a->epilogue == PA_EPI_STORE ? !a->out_lp || a->ldolp % 8 : (!a->out_f32 || !a->resid || a->ldo32 % 4 || a->ldr % 4)) return PA_EINVAL;
+    if (a->colscale_n && (a->epilogue != PA_EPI_STORE || a->colscale_n < 0 || a->colscale_n % 64)) return PA_EINVAL;
+    pa_gemm_args p = *a;
+    p.epilogue = PA_EPI_PARTIAL;
+    p.split_k = s;
+    p.out_f32 = ws;
+    p.ldo32 = a->N;
+    p.bias = nullptr;
+    p.resid = nullptr;
+    p.colscale_n = 0;
+    const int v = pick_nt_variant(a->M, a->N, a->K);
+    p.tune = v == 6 ? 6 : v + 10;            // the 192- / 128-row tiles with A two K-tiles ahead where a slice allows it
+    int rc = pa_gemm_nt(&p, stream);
+    if (rc != PA_OK) return rc;
+    const int64_t vecs = (int64_t)a->M * (a->N / 4);
+    const int blocks = (int)std::min<int64_t>(cdiv(vecs, 256), 2048);
+    if (a->epilogue == PA_EPI_STORE)
+        hipLaunchKernelGGL(nt_splitk_finish_kernel<PA_EPI_STORE>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, ws, s);
+    else
+        hipLaunchKernelGGL(nt_splitk_finish_kernel<PA_EPI_RESID>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, ws, s);
+    return check_launch();
 }
 
 extern "C" int pa_convert_f32(const float* in, void* out, int64_t n, int dtype, void* stream) {

@@ -254,15 +254,45 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.reserved = GEMM_RESERVED | flags
     a.colscale_n, a.colscale = colscale_n, colscale
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
+    # problems that leave most CUs idle (few [M][768] tiles, long K) go through the split-K entry with a workspace
+    ws_n = 0
+    if epilogue in (EPI_STORE, EPI_RESID) and dtype == PA_BF16 and row_mod == 0 and split_k == 1 and not GEMM_TUNE:
+        ws_n = _splitk_ws_floats(a.M, a.N, a.K, epilogue, dtype)
+
+    def launch():
+        if ws_n:
+            ws = _splitk_ws(A.device, ws_n)
+            check(_lib.load().pa_gemm_nt_splitk(C.byref(a), ws.data_ptr(), ws_n, _stream()), "pa_gemm_nt_splitk")
+        else:
+            check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
+
     if GEMM_PROFILE is None:
-        check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
+        launch()
         return
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    check(_lib.load().pa_gemm_nt(C.byref(a), _stream()), "pa_gemm_nt")
+    launch()
     ev1.record()
     kind = _EPI_NAME[epilogue] if not PROFILE_BY_SHAPE else f"{_EPI_NAME[epilogue]}_M{a.M}_N{a.N}_K{a.K}"
     GEMM_PROFILE.setdefault(kind, []).append((ev0, ev1, 2.0 * a.M * a.N * a.K))
+
+
+@functools.lru_cache(maxsize=None)
+def _splitk_ws_floats(M, N, K, epilogue, dtype):
+    return int(_lib.load().pa_gemm_nt_splitk_ws_floats(M, N, K, epilogue, dtype))
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_ws(device, n):
+    """f32 workspace of pa_gemm_nt_splitk, one per (device, stream): the partial tiles live only between the two launches
+    of one call, and calls on one stream are ordered."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _SPLITK_WS[key] = torch.empty(n, device=device, dtype=torch.float32)
+    return ws
 
 
 def gemm_colsum_ws(M, N, device, ws=None):

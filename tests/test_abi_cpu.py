@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
         assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.pa_abi_version() == 2
+    assert lib.pa_abi_version() == 3
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
     assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768
@@ -236,6 +236,17 @@ def test_host_side_queries_answer_without_a_gpu():
     assert lib.pa_gemm_blocked_pre_ok(128, 3072, 768) == 0
     assert lib.pa_gemm_blocked_pre_ok(64 * 474, 3080, 768) == 0
     assert lib.pa_gemm_blocked_pre_ok(0, 3072, 768) == 0
+    # split-K plan of the NT GEMM: only problems that leave most CUs idle and have a long K; never at the headline shapes
+    S, R, G, BF, F32 = _lib.EPI_STORE, _lib.EPI_RESID, _lib.EPI_GELU, _lib.PA_BF16, _lib.PA_F32
+    assert lib.pa_gemm_nt_splitk_plan(12 * 353, 768, 3072, R, BF) == 2        # ESC-50 batch 12: 102 tiles of 128 x 256
+    assert lib.pa_gemm_nt_splitk_plan(12 * 353, 768, 2304, S, BF) == 2
+    assert lib.pa_gemm_nt_splitk_plan(24, 768, 3072, S, BF) == 8              # prefix-only tail: 3 tiles, 48 K-tiles
+    assert lib.pa_gemm_nt_splitk_plan(12 * 353, 768, 768, S, BF) == 1         # short K
+    assert lib.pa_gemm_nt_splitk_plan(64 * 474, 768, 3072, R, BF) == 1        # headline: 474 tiles
+    assert lib.pa_gemm_nt_splitk_plan(12 * 353, 2304, 768, S, BF) == 1
+    assert lib.pa_gemm_nt_splitk_plan(24, 768, 3072, S, F32) == 1 and lib.pa_gemm_nt_splitk_plan(24, 3072, 3072, G, BF) == 1
+    assert lib.pa_gemm_nt_splitk_ws_floats(24, 768, 3072, S, BF) == 8 * 24 * 768
+    assert lib.pa_gemm_nt_splitk_ws_floats(64 * 474, 768, 3072, R, BF) == 0
 
 
 def test_attention_isa_never_touches_in_flight_lds_fragments():

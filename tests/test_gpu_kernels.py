@@ -240,6 +240,40 @@ def test_gemm_store_colscale(dt, M, N, K, ncs):
     assert torch.equal(out[:, ncs:], plain[:, ncs:])
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(4236, 768, 3072, 2), (4236, 768, 2304, 2), (24, 768, 3072, 8), (128, 768, 2304, 6),
+                                          (200, 520, 2048, 5)])
+def test_gemm_split_k_store_and_resid(M, N, K, splits):
+    """pa_gemm_nt_splitk: the [M][768] problems of ESC-50 batch sizes and of the prefix-only tail are cut along K (partial
+    tiles in a workspace + one finishing pass).  Same results as the one-pass kernel up to the order of the f32 partial sums,
+    for both epilogues it covers, incl. the q-prescale columns, an edge tile and a strided output."""
+    lib = ops._lib.load()
+    assert lib.pa_gemm_nt_splitk_plan(M, N, K, EPI_STORE, PA_BF16) == splits
+    A = rnd(M, K, seed=4).bfloat16().to(DEV)
+    Bm = rnd(N, K, seed=5).bfloat16().to(DEV)
+    bias = rnd(N, seed=6).to(DEV)
+    resid = rnd(M, N, seed=7).to(DEV)
+    ref = A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu()
+    ncs = 64 if N > 64 else 0
+    out = torch.full((M, N + 8), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(A, Bm, PA_BF16, EPI_STORE, bias=bias, out_lp=out[:, :N], colscale_n=ncs, colscale=SL2)
+    rs = ref.clone()
+    rs[:, :ncs] *= SL2
+    assert rel_err(out[:, :N], rs) < tol(PA_BF16)
+    assert torch.all(out[:, N:] == 7.0)
+    one = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    old, ops.GEMM_TUNE = ops.GEMM_TUNE, 8          # a forced variant never splits: the one-pass result
+    try:
+        ops.gemm_nt(A, Bm, PA_BF16, EPI_STORE, bias=bias, out_lp=one, colscale_n=ncs, colscale=SL2)
+    finally:
+        ops.GEMM_TUNE = old
+    assert (out[:, :N].float() - one.float()).abs().max() <= 2.0 ** -7 * one.float().abs().max()
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(A, Bm, PA_BF16, EPI_RESID, bias=bias, resid=resid, out_f32=o32)
+    assert rel_err(o32, ref + resid.double().cpu()) < 1e-4          # f32 accumulation of bf16 products: no output rounding
+    ops.gemm_nt(A, Bm, PA_BF16, EPI_RESID, bias=bias, resid=resid, out_f32=resid)      # in place on the residual stream
+    assert torch.equal(resid, o32)
+
+
 def _attn_ref(qkv, B, H, N, scale, d_o=None):
     D = H * 64
     t = qkv.double().cpu().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
