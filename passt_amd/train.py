@@ -7,6 +7,8 @@ AdamW (:104-109) or SGD (model_speed_test, :392).  No autograd graph is built: f
 explicit kernel sequences, parameters and gradients live in flat f32 buffers (one fused optimizer
 launch, per-block all-reduce buckets).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -51,6 +53,7 @@ class TrainStep:
         # ex_audioset.py:488-489); a caller that seeded per rank or loaded different state must not train diverging copies
         self.reducer.broadcast_(self.flat_p)
         self.t = 0
+        self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
         self.base_lr = lr
         net.mark_params_updated()
 
@@ -60,6 +63,18 @@ class TrainStep:
                       self.eps, self.wd, self.t)
         else:
             ops.sgd(self.flat_p[s:e], self.flat_g[s:e], self.lr)
+
+    def _block_done(self, i):
+        """Called by the backward on its finishing stream once bucket i's gradients are complete (head, blocks depth-1 .. 0,
+        patch embedding).  One GPU: update that bucket's parameters right away -- no later kernel of this backward reads
+        them (input gradients use the bf16 copies staged before the step), so the bandwidth-bound optimizer pass runs next
+        to the remaining blocks' GEMMs instead of after them.  Several GPUs: start the bucket's all-reduce."""
+        if self.reducer.world > 1:
+            return self.reducer.on_block_done(i)
+        if self.block_optimizer:
+            s, e = self.reducer.spans[i]
+            if e > s:
+                self._optimizer(s, e)
 
     def close(self):
         """Release the reducer's communicator (C-ABI RCCL transport); torch.distributed groups belong to the caller."""
@@ -103,11 +118,11 @@ class TrainStep:
                 loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, y32[perm_d.long()].contiguous(), lam_d, grad_scale=gs)
             else:
                 loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, grad_scale=gs)
-        passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self.reducer.on_block_done)
         self.t += 1
-        if self.reducer.world == 1:
+        passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self._block_done)
+        if self.reducer.world == 1 and not self.block_optimizer:
             self._optimizer(0, self.flat_p.numel())
-        else:
+        if self.reducer.world > 1:
             # one optimizer launch per all-reduce bucket, in the order the buckets were launched: the update of bucket k runs
             # while buckets k+1.. are still on the wire, so the LAST bucket (block 0 + patch embedding, released only when
             # the backward ends) is covered by ~0.4 ms of optimizer work instead of being exposed in front of one big launch

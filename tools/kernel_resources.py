@@ -2,7 +2,7 @@
 """Registers / scratch / LDS of the kernels in libpasst_amd.so whose name contains one of the given substrings
 (from the code objects' metadata notes; the same extraction as tests/test_abi_cpu.py's no-scratch check).
 
-    python tools/kernel_resources.py streamk attn_ gemm_tn"""
+    python tools/kernel_resources.py [--lib other.so] attn_ gemm_tn"""
 import os
 import re
 import subprocess
@@ -14,8 +14,11 @@ LLVM = "/opt/rocm/lib/llvm/bin/"
 
 
 def main():
-    pats = sys.argv[1:] or [""]
+    argv = sys.argv[1:]
     so = os.path.join(ROOT, "passt_amd", "libpasst_amd.so")
+    if argv and argv[0] == "--lib":
+        so, argv = argv[1], argv[2:]
+    pats = argv or [""]
     with tempfile.TemporaryDirectory() as d:
         fat = os.path.join(d, "fat.bin")
         subprocess.run([LLVM + "llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", so, os.path.join(d, "copy.so")], check=True)
