@@ -199,8 +199,8 @@ def main():
     ap.add_argument("--no-mel", action="store_true", help="feed spectrograms (reference model_speed_test style)")
     ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sgd"])
     ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="weight-gradient kernels on a second stream (+2.4%% throughput; concurrent kernels make the "
-                         "per-launch roofline timing inexact, hence off by default)")
+                    help="weight-gradient kernels on a second stream, one launch per problem (A/B only: since the batched "
+                         "per-block launch it measures the same as the default, profiles/r03_finish_stream_experiment.txt)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
