@@ -2,9 +2,9 @@
 # sustained run, attention counters, the GPU test log.  Output: gpurun_out/r03/
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/r03f
 mkdir -p $O
-bash tools/collect_profiles.sh gpurun_out/r03 > $O/collect.log 2>&1
+bash tools/collect_profiles.sh gpurun_out/r03f > $O/collect.log 2>&1
 python bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/bench_c2_sustained_400.json.log
 python bench.py --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4.json.log
 python bench.py --config c4_ref --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c4_ref.json.log
@@ -23,5 +23,5 @@ for d in pa1 pa2; do python tools/rocpd_stats.py "$(find /tmp/$d -name '*.db' | 
 python tools/debug_attn.py 64 > $O/attention_stress.txt 2>&1
 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|skipped|^FAILED|^ERROR" | tail -5 > $O/pytest_gpu.txt
 cp gpurun_out/kernel_parity_metrics.json $O/ 2>/dev/null; cp gpurun_out/model_parity_metrics.json $O/ 2>/dev/null
-bash tools/power_trace.sh 600 > $O/power_trace.txt 2>&1
+python tools/bench_vs_vendor.py > $O/vs_vendor.json 2>/dev/null
 ls -la $O; cat $O/pytest_gpu.txt; tail -1 $O/bench_c2.log | cut -c1-200; for f in $O/bench_*.json.log; do echo $f; cut -c1-160 $f; done
