@@ -331,6 +331,8 @@ def main():
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
+                       "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
+                                       if ops.GEMM_RESERVED & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
                        "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
             "algorithmic_gflop_per_clip": round(gflop_clip, 2),
             "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),

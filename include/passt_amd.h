@@ -184,6 +184,10 @@ typedef struct {
  * pa_gemm_blocked_pre_elems(M, N) elements (rows padded to whole tiles), ldolp / ldaux ignored.  Only for shapes where
  * pa_gemm_blocked_pre_ok(M, N, K) returns 1 (bf16, tune = 0); otherwise pa_gemm_nt returns PA_EUNSUPPORTED. */
 #define PA_GEMM_BLOCKED_PRE 0x100
+/* pa_gemm_nt, role-split kernels: one work item per workgroup (hardware dispatch) instead of the persistent form, for callers
+ * that run another kernel next to the GEMMs -- the gradient all-reduce of data-parallel training (ex_audioset.py:488-489): a
+ * persistent launch whose workgroups cannot all be resident at once takes twice as long.  Same results. */
+#define PA_GEMM_NO_PERSIST 0x400
 int pa_gemm_blocked_pre_ok(int M, int N, int K);
 int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);

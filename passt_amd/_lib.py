@@ -98,7 +98,8 @@ SIGNATURES = {
     "pa_comm_destroy": (i32, [vp]),
     "pa_comm_last_error": (C.c_char_p, []),
 }
-GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flag (include/passt_amd.h)
+GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flags (include/passt_amd.h)
+GEMM_NO_PERSIST = 0x400
 COMM_ID_BYTES = 128
 
 _lib = None

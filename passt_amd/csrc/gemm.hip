@@ -1148,8 +1148,14 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>), dim3(std::min(total, 256)), dim3(512), LDS_BYTES, st, a, tiles_m,
-                       tiles_n, nwg, per, total);
+    // PA_GEMM_NO_PERSIST (a.reserved) / PA_NT_PERSISTENT=0: one work item per workgroup, handed out by the hardware as CUs free
+    // up, instead of 256 resident workgroups walking their item lists.  The persistent form assumes it owns every CU: when
+    // another kernel (an RCCL all-reduce on the communication stream) holds R of them, R of its workgroups only start after the
+    // others have finished ALL their items and the launch takes twice as long; one item per workgroup degrades by R / 256.
+    static const bool persist_env = [] { const char* e = getenv("PA_NT_PERSISTENT"); return !e || atoi(e) != 0; }();
+    const bool persistent = persist_env && !(a.reserved & PA_GEMM_NO_PERSIST);
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>), dim3(persistent ? std::min(total, 256) : total), dim3(512), LDS_BYTES, st, a,
+                       tiles_m, tiles_n, nwg, per, total);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
     return rc;

@@ -52,6 +52,12 @@ class TrainStep:
         # identical replicas: rank 0's parameters everywhere (what Lightning's DDP wrapper does at construction,
         # ex_audioset.py:488-489); a caller that seeded per rank or loaded different state must not train diverging copies
         self.reducer.broadcast_(self.flat_p)
+        if self.reducer.world > 1 and os.environ.get("PASST_AMD_DDP_PERSISTENT") != "1":
+            # the all-reduce kernels of the communication stream take CUs while the backward runs: GEMMs go out one work
+            # item per workgroup (the hardware hands them to whatever CUs are free: -1.6 % alone on one GPU) instead of as 256
+            # resident workgroups, which would wait for the occupied CUs and double the launch (PA_GEMM_NO_PERSIST).
+            # Process-wide: every pa_gemm_nt call of this process from here on.
+            ops.GEMM_RESERVED |= ops._lib.GEMM_NO_PERSIST
         self.t = 0
         self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
         self.base_lr = lr

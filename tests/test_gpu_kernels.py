@@ -274,6 +274,36 @@ def test_gemm_split_k_store_and_resid(M, N, K, splits):
     assert torch.equal(resid, o32)
 
 
+@pytest.mark.parametrize("M,N,K", [(64 * 474, 768, 768), (2000, 3072, 768), (1999, 2304, 256)])
+def test_gemm_one_item_per_workgroup_is_bit_identical(M, N, K):
+    """PA_GEMM_NO_PERSIST (what TrainStep sets when it all-reduces next to the backward): the role-split kernels launched
+    with one work item per workgroup instead of 256 resident ones -- same items, same arithmetic, same bits, for every epilogue."""
+    A = rnd(M, K, seed=41).bfloat16().to(DEV)
+    Bm = rnd(N, K, seed=42).bfloat16().to(DEV)
+    bias = rnd(N, seed=43).to(DEV)
+    resid = rnd(M, N, seed=44).to(DEV)
+
+    def run():
+        o1 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(A, Bm, PA_BF16, EPI_STORE, bias=bias, out_lp=o1)
+        o2 = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(A, Bm, PA_BF16, EPI_RESID, bias=bias, resid=resid, out_f32=o2)
+        pre, act = torch.empty_like(o1), torch.empty_like(o1)
+        ops.gemm_nt(A, Bm, PA_BF16, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
+        return o1, o2, pre, act
+
+    base = run()
+    old = ops.GEMM_RESERVED
+    ops.GEMM_RESERVED = old | ops._lib.GEMM_NO_PERSIST
+    try:
+        other = run()
+    finally:
+        ops.GEMM_RESERVED = old
+    for x, y in zip(base, other):
+        assert torch.equal(x, y)
+    assert rel_err(base[1], A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu() + resid.double().cpu()) < 1e-4
+
+
 def _attn_ref(qkv, B, H, N, scale, d_o=None):
     D = H * 64
     t = qkv.double().cpu().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
