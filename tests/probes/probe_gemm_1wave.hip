@@ -29,7 +29,23 @@ template <int TM2> struct Geo {
     static constexpr int LDS = 2 * STAGE;
 };
 
-template <int TM2>
+// 16-byte LDS read the compiler does not track: issued where it is written, settled by settle() (a counted s_waitcnt that
+// names the fragments as operands, so no use of them can be scheduled above it).  With plain loads the compiler waits with
+// lgkmcnt(0) in front of every MFMA group, i.e. also for the reads it has just issued for the NEXT substep.
+__device__ __forceinline__ bf16x8 lds_read_asm(uint32_t addr, int imm) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(imm));
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int TM2> __device__ __forceinline__ void settle(bf16x8 (&fa)[TM2], bf16x8 (&fb)[4], int pending) {
+    if constexpr (TM2 == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) : "i"(pending));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) : "i"(pending));
+}
+
+template <int TM2, bool ASMRD>
 __global__ __launch_bounds__(256) void gemm_1wave_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ C,
                                                          int M, int N, int K, int tiles_n, int store) {
     using G = Geo<TM2>;
@@ -70,12 +86,30 @@ __global__ __launch_bounds__(256) void gemm_1wave_kernel(const bf16* __restrict_
 
     const int half = lane >> 5, r31 = lane & 31, rsw = swz_f128(r31);      // rows 32 apart share the swizzle term
     const int adrA = (wr * (32 * TM2) + r31) * 128, adrB = G::A_BYTES + (wc * 128 + r31) * 128;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto read_frags = [&](const char* st, int s, bf16x8 (&fa)[TM2], bf16x8 (&fb)[4]) {
         const int coff = ((s * 2 + half) ^ rsw) << 4;
+        if constexpr (ASMRD) {
+            const uint32_t base = lds0 + (uint32_t)(st - smem) + (uint32_t)coff;
+            const uint32_t pa = base + (uint32_t)adrA, pb = base + (uint32_t)adrB;
 #pragma unroll
-        for (int i = 0; i < TM2; ++i) fa[i] = *(const bf16x8*)(st + adrA + i * 32 * 128 + coff);
+            for (int i = 0; i < TM2; ++i) fa[i] = lds_read_asm(pa, i * 32 * 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(st + adrB + j * 32 * 128 + coff);
+            for (int j = 0; j < 4; ++j) fb[j] = lds_read_asm(pb, j * 32 * 128);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM2; ++i) fa[i] = *(const bf16x8*)(st + adrA + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(st + adrB + j * 32 * 128 + coff);
+        }
+    };
+    constexpr int NRD = TM2 + 4;             // reads per substep
+    auto ready = [&](bf16x8 (&fa)[TM2], bf16x8 (&fb)[4], int pending) {        // fragments usable; `pending` younger reads may fly
+        if constexpr (ASMRD) {
+            __builtin_amdgcn_sched_barrier(0);
+            settle<TM2>(fa, fb, pending);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     f32x16 acc[TM2][4];
@@ -105,13 +139,17 @@ __global__ __launch_bounds__(256) void gemm_1wave_kernel(const bf16* __restrict_
         const char* stn = smem + ((t + 1) & 1) * G::STAGE;
         // substep 0: reads of substep 1 in flight under the MFMAs of substep 0, and so on
         read_frags(st, 1, fa1, fb1);
+        ready(fa0, fb0, NRD);
         mfmas(fa0, fb0, 0, 4);
         read_frags(st, 2, fa0, fb0);
+        ready(fa1, fb1, NRD);
         mfmas(fa1, fb1, 0, 4);
         read_frags(st, 3, fa1, fb1);
+        ready(fa0, fb0, NRD);
         mfmas(fa0, fb0, 0, 4);
         // substep 3: first half, then the K-tile hand-over (everybody is done reading stage t; tile t+1 has landed),
         // the first reads of tile t+1 and the request for tile t+2, then the second half
+        ready(fa1, fb1, 0);
         mfmas(fa1, fb1, 0, 2);
         if (t + 1 < nk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own DMA pieces of tile t+1 landed; own reads of tile t done
@@ -119,6 +157,7 @@ __global__ __launch_bounds__(256) void gemm_1wave_kernel(const bf16* __restrict_
             read_frags(stn, 0, fa0, fb0);
             if (t + 2 < nk) dma(t & 1, t + 2);
         }
+        if constexpr (ASMRD) __builtin_amdgcn_sched_barrier(0);
         mfmas(fa1, fb1, 2, 4);
     }
 
@@ -151,12 +190,12 @@ static float urand(uint32_t& s) {
     return ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
 }
 
-template <int TM2>
+template <int TM2, bool ASMRD>
 static void run(int M, int N, int K, const bf16* dA, const bf16* dB, float* dC, const std::vector<bf16>& hA, const std::vector<bf16>& hB) {
     using G = Geo<TM2>;
-    CK(hipFuncSetAttribute((const void*)gemm_1wave_kernel<TM2>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    CK(hipFuncSetAttribute((const void*)(gemm_1wave_kernel<TM2, ASMRD>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
     const int tiles_m = (M + G::TBM - 1) / G::TBM, tiles_n = (N + 255) / 256, grid = tiles_m * tiles_n;
-    hipLaunchKernelGGL(gemm_1wave_kernel<TM2>, dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, 1);
+    hipLaunchKernelGGL((gemm_1wave_kernel<TM2, ASMRD>), dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, 1);
     CK(hipDeviceSynchronize());
     std::vector<float> hC((size_t)M * N);
     CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
@@ -172,16 +211,17 @@ static void run(int M, int N, int K, const bf16* dA, const bf16* dB, float* dC, 
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(gemm_1wave_kernel<TM2>, dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, mode);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((gemm_1wave_kernel<TM2, ASMRD>), dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, mode);
         CK(hipEventRecord(e0));
         const int iters = 20;
-        for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(gemm_1wave_kernel<TM2>, dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, mode);
+        for (int w = 0; w < iters; ++w) hipLaunchKernelGGL((gemm_1wave_kernel<TM2, ASMRD>), dim3(grid), dim3(256), G::LDS, 0, dA, dB, dC, M, N, K, tiles_n, mode);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-        printf("tile %dx256  M=%d N=%d K=%d  tiles=%d (%.2f rounds)  %s: %.1f us  %.1f TF/s   (max abs err %.3g of %.3g)\n", G::TBM, M, N, K, grid,
+        printf("tile %dx256 %s  M=%d N=%d K=%d  tiles=%d (%.2f rounds)  %s: %.1f us  %.1f TF/s   (max abs err %.3g of %.3g)\n", G::TBM,
+               ASMRD ? "counted waits " : "compiler waits", M, N, K, grid,
                grid / 256.0, mode ? "K loop + f32 store" : "K loop only       ", us, tf, maxerr, maxref);
     }
 }
@@ -202,8 +242,10 @@ int main() {
         CK(hipMalloc(&dC, (size_t)M * N * 4));
         CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
-        run<4>(M, N, K, dA, dB, dC, hA, hB);
-        run<3>(M, N, K, dA, dB, dC, hA, hB);
+        run<4, false>(M, N, K, dA, dB, dC, hA, hB);
+        run<4, true>(M, N, K, dA, dB, dC, hA, hB);
+        run<3, false>(M, N, K, dA, dB, dC, hA, hB);
+        run<3, true>(M, N, K, dA, dB, dC, hA, hB);
         CK(hipFree(dA));
         CK(hipFree(dB));
         CK(hipFree(dC));
