@@ -2,8 +2,12 @@
 """bench.py -- headline benchmark of the PaSST training hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W            (self-launching: forks one rank per GPU, like the reference's
+                                                              DDP=N python ex_audioset.py, ex_audioset.py:499-524)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)
+Whatever goes wrong (fewer than N devices, a rank dying), the process prints ONE JSON line with an "error" field and exits
+non-zero -- never a bare exit.
 
 Metric (BASELINE.json): clips/s of 10 s @ 32 kHz, forward+backward, passt_s
 (passt_s_swa_p16_128_ap476: 768/12/12, patch 16 stride 10, s_patchout_t=40 s_patchout_f=4 => 474
@@ -24,7 +28,7 @@ Besides the contract line it reports
 --config c4 | c4_ref | c5 runs the other BASELINE.json configurations (ViT-L geometry, the reference's passt_l,
 ESC-50 fine-tune); their lines are committed under profiles/.
   cpu_baseline : the oracle (CPU restatement of the reference, oracle/passt_oracle.py) timed on this
-                 host on a bounded sample of the same workload (train-mode fwd+bwd, B=4 per iteration).
+                 host on a bounded sample of the same workload (train-mode fwd+bwd, B=2 per iteration).
 """
 import argparse
 import contextlib
@@ -183,6 +187,121 @@ def committed_traffic(name, sources):
     return tj["hbm_bytes_per_launch"], f"profiles/{name} (" + tj.get("method", "rocprofv3 --pmc") + ")"
 
 
+class AutogradStep:
+    """What an UNMODIFIED ex_audioset.py / ex_esc50.py runs per step when models.passt / models.preprocess resolve to
+    passt_amd (the drop-in path): the caller's own torch code around ``net(x)`` -- mel_forward (ex_audioset.py:142-153),
+    my_mixup + spectrogram / target mixing (:171-183, helpers/mixup.py:5-12), F.binary_cross_entropy_with_logits (:181-186)
+    or the CE-mixup of ex_esc50.py:159-165, ``loss.backward()`` through the ONE autograd node of the network,
+    torch.optim.AdamW over ``net.parameters()`` (:104-109; Lightning's zero_grad / step order).  Under torch.autocast, as
+    Lightning's precision=16 does.  N > 1: passt_amd.ddp.attach(net) -- the node all-reduces per-block buckets from inside
+    its backward (no DistributedDataParallel wrapper).  Same .step(x, y) / .reducer / .close() surface as TrainStep."""
+
+    def __init__(self, net, mel, lr, weight_decay, loss, mixup_alpha, precision, comm_dtype, transport, optimizer="adamw"):
+        from passt_amd import ddp
+        self.net, self.mel, self.loss, self.alpha = net, mel, loss, mixup_alpha
+        self.autocast = precision == "bf16"
+        net.precision = None                    # follow torch.autocast, like the reference under Lightning AMP
+        self.reducer = ddp.attach(net, comm_dtype=comm_dtype, transport=transport)
+        if optimizer == "adamw":
+            self.opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=weight_decay)
+        else:
+            self.opt = torch.optim.SGD(net.parameters(), lr=lr)
+
+    def step(self, x, y):
+        F = torch.nn.functional
+        net = self.net
+        if self.mel is not None:
+            old_shape = x.size()
+            x = self.mel(x.reshape(-1, old_shape[2]))
+            x = x.reshape(old_shape[0], old_shape[1], x.shape[1], x.shape[2])
+        B = len(y)
+        perm = torch.randperm(B)
+        lam = np.random.beta(self.alpha, self.alpha, B).astype(np.float32)
+        lam = torch.from_numpy(np.maximum(lam, 1.0 - lam)).to(x.device)
+        x = x * lam.reshape(B, 1, 1, 1) + x[perm] * (1.0 - lam.reshape(B, 1, 1, 1))
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
+            y_hat, _ = net(x)
+            if self.loss == "bce":
+                y_mix = y * lam.reshape(B, 1) + y[perm] * (1.0 - lam.reshape(B, 1))
+                loss = F.binary_cross_entropy_with_logits(y_hat, y_mix, reduction="none").mean()
+            else:
+                sl = F.cross_entropy(y_hat, y, reduction="none") * lam + F.cross_entropy(y_hat, y[perm], reduction="none") * (1.0 - lam)
+                loss = sl.mean()
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def close(self):
+        from passt_amd import ddp
+        ddp.detach(self.net)
+
+
+def error_line(args, msg, **extra):
+    """The contract's ONE JSON line when no measurement exists: same keys, value null, the reason in `error`."""
+    cfgd = CONFIGS[args.config]
+    print(json.dumps({"metric": cfgd["metric"], "value": None, "unit": "clips/s", "n_gpus": args.gpus, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                      "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config},
+                      "error": msg, **extra}), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: fork one rank per GPU ourselves -- what the reference's own
+    entry point does (`DDP=N python ex_audioset.py`, ex_audioset.py:499-524: MASTER_ADDR 127.0.0.1, a random port, one child
+    per rank, rank r on device r).  Children are fresh interpreters of this same command line with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, i.e. exactly what torch.distributed.run would have started; rank 0's stdout (the ONE JSON
+    line) is passed through, the other ranks' stdout goes to stderr.  A rank that dies takes the job down: the survivors
+    are killed (they would hang in a collective) and an error line is printed.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    dry = os.environ.get("PASST_AMD_BENCH_DRY_GLOO") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if dry else n):
+        error_line(args, f"--gpus {n} needs {n} visible HIP devices, this box has {have}"
+                         + (" (PASST_AMD_BENCH_DRY_GLOO=1 runs every rank on device 0 over gloo: needs one)" if dry else ""),
+                   devices_visible=have)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PASST_AMD_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    failed = None
+    deadline = time.time() + float(os.environ.get("PASST_AMD_BENCH_TIMEOUT_S", "1500"))
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+        elif time.time() > deadline:
+            failed = "timed out"
+        if failed or all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out0 = procs[0].stdout.read().decode(errors="replace")
+    for p in procs:
+        p.wait()
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if failed or len(lines) != 1:
+        error_line(args, failed or f"rank 0 printed {len(lines)} JSON lines", launcher="self (one child per rank)")
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,8 +320,32 @@ def main():
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient kernels on a second stream, one launch per problem (A/B only: since the batched "
                          "per-block launch it measures the same as the default, profiles/r03_finish_stream_experiment.txt)")
+    ap.add_argument("--path", default="trainstep", choices=["trainstep", "autograd"],
+                    help="trainstep: passt_amd.train.TrainStep (fused mixup / loss / AdamW, no autograd graph).  autograd: what an "
+                         "UNMODIFIED ex_audioset.py runs -- mel -> torch mixup -> net(x) (one autograd Function) -> torch BCE -> "
+                         "loss.backward() -> torch.optim.AdamW, gradients all-reduced per block from inside the backward "
+                         "(passt_amd.ddp.attach)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args))
+        if not torch.cuda.is_available():
+            error_line(args, "no HIP device visible (passt_amd has no CPU path)", devices_visible=0)
+            sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        run(args)
+    except BaseException as e:      # noqa: BLE001 -- the contract line must exist whatever happened
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        # under the self-launcher the parent prints the line (it also sees ranks that were killed)
+        if rank == 0 and os.environ.get("PASST_AMD_BENCH_CHILD") != "1":
+            error_line(args, f"{type(e).__name__}: {e}"[:500])
+        raise
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # dry run of the N > 1 code path on a box with ONE GPU (tests/test_gpu_ddp.py::test_bench_multi_rank_dry_run): every rank
@@ -212,8 +355,9 @@ def main():
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise RuntimeError(f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
+    if not dry and torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP devices are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -244,9 +388,13 @@ def main():
             fmin_aug_range=10, fmax_aug_range=2000, **cfgd["mel_kw"]).to(dev).train()      # ex_audioset.py:66-69 / ex_esc50.py:62-66
     net.precision = args.precision
     net.overlap_wgrad = args.overlap_wgrad
-    # TrainStep broadcasts rank 0's parameters itself (identical replicas)
-    ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
-                   loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport)
+    # TrainStep / ddp.attach broadcast rank 0's parameters themselves (identical replicas)
+    if args.path == "autograd":
+        ts = AutogradStep(net, mel, lr=2e-5, weight_decay=1e-4, loss=cfgd["loss"], mixup_alpha=0.3, precision=args.precision,
+                          comm_dtype=args.comm_dtype, transport=args.transport, optimizer=args.optimizer)
+    else:
+        ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
+                       loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport)
     B = args.batch or cfgd["batch"]
     frames = 998 if cfgd["clip"] == CLIP_SAMPLES else 1 + (cfgd["clip"] - 1) // 320     # --no-mel: the reference's speed-test shape
     if args.no_mel:
@@ -288,7 +436,7 @@ def main():
     # ---- outside the timed region -------------------------------------------------------------------------------
     # (a) N > 1: MEASURED per-bucket all-reduce (HIP events: launch -> released, and how long the compute stream was
     #     blocked on it) of one extra instrumented step, next to the modelled curve
-    allreduce = None
+    allreduce = rccl = None
     if world > 1:
         ts.reducer.start_timing()
         with warnings.catch_warnings():
@@ -297,15 +445,29 @@ def main():
         barrier()
         buckets = ts.reducer.timing_summary()
         ts.reducer.timing = None
+        # the same buckets once more with the GPU otherwise idle: what the wire alone costs (the in-step figure above is
+        # launch -> released and therefore includes queueing behind the backward's kernels: it under-reports the bus)
+        idle = ts.reducer.measure_idle()
+        comm_info = ts.reducer.comm_info()
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": f"cuda:{local_rank}", "name": props.name, "gcn_arch": getattr(props, "gcnArchName", None),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "comm_nranks": comm_info.get("nranks"), "comm_rank": comm_info.get("rank")}
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
         if rank == 0:
             allreduce = {"kind": "MEASURED on this run (one instrumented step after the timed region, rank 0)",
                          "transport": args.transport, "wire_dtype": args.comm_dtype, "buckets": buckets,
                          "bytes_per_step": sum(b["bytes"] for b in buckets),
                          "exposed_wait_ms_per_step": round(sum(b["exposed_wait_ms"] for b in buckets), 4),
-                         "bus_GBps_min_max": [min(b["bus_GBps"] for b in buckets), max(b["bus_GBps"] for b in buckets)] if buckets else None}
+                         "bus_GBps_min_max": [min(b["bus_GBps"] for b in buckets), max(b["bus_GBps"] for b in buckets)] if buckets else None,
+                         "idle": {"kind": "the same buckets all-reduced with the compute stream idle (best of 3 after a warm-up pass)",
+                                  "buckets": idle, "ms_per_step": round(sum(b["ms"] for b in idle), 4),
+                                  "bus_GBps_total": round(2.0 * (world - 1) / world * sum(b["bytes"] for b in idle)
+                                                          / max(sum(b["ms"] for b in idle), 1e-6) / 1e6, 1) if idle else None}}
+            rccl = dict(comm_info, ranks=devices)
     # (b) the parity mode (exact-f32 MFMA, <= 3e-6 of the fp32 reference: the bound north_star states) trains this fast
     parity_clips = None
-    if world == 1 and args.config == "c2" and args.precision == "bf16" and not args.no_cpu_baseline:
+    if world == 1 and args.config == "c2" and args.precision == "bf16" and not args.no_cpu_baseline and args.path == "trainstep":
         net.precision = "fp32"
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -331,8 +493,11 @@ def main():
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
+                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW)" if args.path == "trainstep" else
+                                "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
+                                + ("AdamW" if args.optimizer == "adamw" else "SGD") + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
                        "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
-                                       if ops.GEMM_RESERVED & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
+                                       if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
                        "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
             "algorithmic_gflop_per_clip": round(gflop_clip, 2),
             "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -406,8 +571,11 @@ def main():
             out["parity_mode_clips_s"] = parity_clips     # same step, precision="fp32": what meets the <= 1e-3 parity bound
         if allreduce is not None:
             out["allreduce_measured"] = allreduce
+            out["rccl"] = rccl
         print(json.dumps(out), flush=True)
+    ts.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 3   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
-                            * 3: pa_gemm_nt_splitk* */
+#define PA_ABI_VERSION 4   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
+                            * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -380,6 +380,10 @@ int pa_comm_init(const void* id, int rank, int world, void** comm_out);
 /* buf[count] (dtype PA_F32 or PA_BF16) <- sum over ranks, in place, asynchronous and ordered on `stream` */
 int pa_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, void* stream);
 int pa_comm_destroy(void* comm);
+/* What the communicator itself reports (ncclGetVersion / ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the evidence
+ * bench.py prints for an N > 1 run.  Any out pointer may be NULL; comm == NULL with only rccl_version asked returns the
+ * version of the RCCL the library resolved (e.g. 22703 = 2.27.3). */
+int pa_comm_info(void* comm, int* rccl_version, int* nranks, int* rank, int* device);
 /* text of the last PA_ECOMM on the calling thread */
 const char* pa_comm_last_error(void);
 

@@ -57,11 +57,15 @@ def kaldi_get_mel_banks(num_bins, window_length_padded, sample_freq, low_freq, h
 
 
 def mask_along_axis(specgram, mask_param, mask_value, axis):
-    """Restatement of torchaudio.functional.mask_along_axis (0.13.1, p=1.0), the path taken by
-    FrequencyMasking/TimeMasking(iid_masks=True) on the reference's 3-D (B, mel, T) input
-    (models/preprocess.py:50,54,81-82).  Consumes two CPU ``torch.rand(1)``."""
+    """Restatement of torchaudio.functional.mask_along_axis (0.13.1 with p = 1.0; 0.11.0 has no p at all), the path taken
+    by FrequencyMasking/TimeMasking(iid_masks=True) on the reference's 3-D (B, mel, T) input
+    (models/preprocess.py:50,54,81-82).  Consumes two CPU ``torch.rand(1)``.
+    mask_param is NOT clamped to the axis length: 0.13.1's ``_get_mask_param`` returns it unchanged for p == 1.0 (the
+    transforms' default, which the reference uses) and 0.11.0 never clamps; for an axis shorter than mask_param the band
+    start ``rand * (size - value)`` can therefore be negative (truncated toward zero by ``.long()``) and the band can
+    cover the whole axis.  torchaudio's source is not on this machine: this function remains a restatement (parity
+    UNPINNED)."""
     assert axis in (1, 2)
-    mask_param = min(mask_param, int(specgram.shape[axis]))
     if mask_param < 1:
         return specgram
     shape = specgram.size()
@@ -79,8 +83,7 @@ def mask_along_axis(specgram, mask_param, mask_value, axis):
 
 
 def draw_mask_params(mask_param, size):
-    """The (start, end) a ``mask_along_axis`` call draws -- same two ``torch.rand(1)`` calls."""
-    mask_param = min(mask_param, int(size))
+    """The (start, end) a ``mask_along_axis`` call draws -- same two ``torch.rand(1)`` calls (no clamp, see above)."""
     if mask_param < 1:
         return 0, 0
     value = torch.rand(1) * mask_param
@@ -266,6 +269,17 @@ def mixup_apply(x, y, rn_indices, lam):
 def bce_loss(logits, target):
     """ex_audioset.py:184-186: BCE-with-logits, reduction none, then mean over (B, C)."""
     return F.binary_cross_entropy_with_logits(logits, target, reduction="none").mean()
+
+
+def ce_mixup_loss(logits, target, rn_indices=None, lam=None):
+    """ex_esc50.py:159-169: class-index targets; with mixup the two cross-entropies (own label, partner's label) are mixed
+    per sample with lam / (1 - lam), without mixup plain cross-entropy; mean over the batch."""
+    if rn_indices is None:
+        return F.cross_entropy(logits, target, reduction="none").mean()
+    B = logits.shape[0]
+    sl = (F.cross_entropy(logits, target, reduction="none") * lam.reshape(B)
+          + F.cross_entropy(logits, target[rn_indices], reduction="none") * (1.0 - lam.reshape(B)))
+    return sl.mean()
 
 
 def to_torch(sd_np, dtype=torch.float32, requires_grad=False):

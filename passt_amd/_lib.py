@@ -96,6 +96,7 @@ SIGNATURES = {
     "pa_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
     "pa_allreduce_bucket": (i32, [vp, vp, i64, i32, vp]),
     "pa_comm_destroy": (i32, [vp]),
+    "pa_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "pa_comm_last_error": (C.c_char_p, []),
 }
 GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flags (include/passt_amd.h)
@@ -122,7 +123,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype, fn.argtypes = res, args
-    if lib.pa_abi_version() != 3:      # include/passt_amd.h PA_ABI_VERSION
+    if lib.pa_abi_version() != 4:      # include/passt_amd.h PA_ABI_VERSION
         raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -19,6 +19,10 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId*);
 ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
 ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
 ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclGetVersion(int*);
+ncclResult_t ncclCommCount(const ncclComm_t, int*);
+ncclResult_t ncclCommUserRank(const ncclComm_t, int*);
+ncclResult_t ncclCommCuDevice(const ncclComm_t, int*);
 const char* ncclGetErrorString(ncclResult_t);
 }
 #endif
@@ -37,6 +41,10 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     std::string error;
 };
 Rccl g_rccl;
@@ -52,6 +60,7 @@ void load_rccl() {
     if (!g_rccl.handle) { g_rccl.error = std::string("cannot load librccl.so: ") + dlerror(); return; }
 #define PA_SYM(f) g_rccl.f = (decltype(g_rccl.f))dlsym(g_rccl.handle, "nccl" #f); if (!g_rccl.f) g_rccl.error = "librccl.so lacks nccl" #f;
     PA_SYM(GetUniqueId) PA_SYM(CommInitRank) PA_SYM(AllReduce) PA_SYM(CommDestroy) PA_SYM(GetErrorString)
+    PA_SYM(GetVersion) PA_SYM(CommCount) PA_SYM(CommUserRank) PA_SYM(CommCuDevice)
 #undef PA_SYM
 }
 
@@ -92,6 +101,16 @@ extern "C" int pa_allreduce_bucket(void* comm, void* buf, int64_t count, int dty
     if (int rc = ready()) return rc;
     return check_nccl(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == PA_F32 ? ncclFloat32 : ncclBfloat16, ncclSum, (ncclComm_t)comm,
                                       (hipStream_t)stream), "ncclAllReduce");
+}
+
+extern "C" int pa_comm_info(void* comm, int* rccl_version, int* nranks, int* rank, int* device) {
+    if (int rc = ready()) return rc;
+    if (rccl_version) if (int rc = check_nccl(g_rccl.GetVersion(rccl_version), "ncclGetVersion")) return rc;
+    if (!comm) return (nranks || rank || device) ? PA_EINVAL : PA_OK;      // version only: no communicator needed
+    if (nranks) if (int rc = check_nccl(g_rccl.CommCount((ncclComm_t)comm, nranks), "ncclCommCount")) return rc;
+    if (rank) if (int rc = check_nccl(g_rccl.CommUserRank((ncclComm_t)comm, rank), "ncclCommUserRank")) return rc;
+    if (device) if (int rc = check_nccl(g_rccl.CommCuDevice((ncclComm_t)comm, device), "ncclCommCuDevice")) return rc;
+    return PA_OK;
 }
 
 extern "C" int pa_comm_destroy(void* comm) {

@@ -94,10 +94,9 @@ class RcclAbiTransport:
             self.comm = None
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:       # interpreter shutdown: the process is going away with the communicator
-            pass
+        # never tear a communicator down from the garbage collector (peers may already have exited: ncclCommDestroy would
+        # hang); owners call close() -- TrainStep.close(), ddp.detach()
+        pass
 
 
 class GradReducer:
@@ -106,16 +105,21 @@ class GradReducer:
     link (172 MB instead of 345 MB per step for passt_s), at bf16 rounding of the exchanged sums (not the reference's
     behaviour: opt-in)."""
 
-    def __init__(self, flat_grads, named_sizes, depth, process_group=None, comm_dtype="fp32", transport="torch"):
+    def __init__(self, flat_grads, named_sizes, depth, process_group=None, comm_dtype="fp32", transport="torch", device=None):
         """transport "torch": torch.distributed collectives (backend nccl == RCCL on ROCm, gloo on CPU / in the tests);
-        "rccl_abi": the library's C-ABI collective entry (RcclAbiTransport)."""
+        "rccl_abi": the library's C-ABI collective entry (RcclAbiTransport).  ``flat_grads`` may be None when the owner
+        rebinds ``self.flat`` before every backward (the autograd path hands autograd a fresh buffer per step: attach());
+        pass ``device`` then."""
         assert comm_dtype in ("fp32", "bf16") and transport in ("torch", "rccl_abi")
         self.flat = flat_grads
+        self.device = torch.device(device) if device is not None else flat_grads.device
+        self.total = sum(n for _, n in named_sizes)
         self.spans = bucket_layout(named_sizes, depth)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype
-        self.abi = RcclAbiTransport(flat_grads.device, process_group) if (transport == "rccl_abi" and self.world > 1) else None
+        self.transport = transport
+        self.abi = RcclAbiTransport(self.device, process_group) if (transport == "rccl_abi" and self.world > 1) else None
         self.pending = []
         self._wires = {}
         self.timing = None
@@ -160,7 +164,7 @@ class GradReducer:
         key = (len(self.pending), n)
         buf = self._wires.get(key)
         if buf is None:
-            buf = self._wires[key] = torch.empty(n, device=self.flat.device, dtype=torch.bfloat16)
+            buf = self._wires[key] = torch.empty(n, device=self.device, dtype=torch.bfloat16)
         return buf
 
     def _finish(self, item):
@@ -222,14 +226,118 @@ class GradReducer:
             self.abi.close()
             self.abi = None
 
+    def launch_order(self):
+        """bucket ids in the order the backward completes them: head, blocks depth-1 .. 0, patch embedding"""
+        return sorted(self.spans, key=lambda b: (b != max(self.spans), -b))
+
+    def comm_info(self):
+        """What the communicator itself reports, for bench.py's N > 1 line: {backend, rccl_version, nranks, rank}.  C-ABI
+        transport: ncclGetVersion / ncclCommCount / ncclCommUserRank of the live communicator (pa_comm_info);
+        torch transport: the process group's backend and size, RCCL version from torch.cuda.nccl."""
+        info = {"transport": self.transport, "nranks": self.world, "rank": dist.get_rank(self.group) if dist.is_initialized() else 0}
+        if self.abi is not None:
+            import ctypes as C
+            from . import _lib
+            v, n, r, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            _lib.check(_lib.load().pa_comm_info(self.abi.comm, C.byref(v), C.byref(n), C.byref(r), C.byref(d)), "pa_comm_info")
+            info.update(backend="rccl (C ABI: pa_comm_*)", rccl_version=v.value, nranks=n.value, rank=r.value, device=d.value,
+                        source="ncclGetVersion / ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the live communicator")
+        elif dist.is_initialized():
+            be = dist.get_backend(self.group)
+            info.update(backend=be, source="torch.distributed process group")
+            if be == "nccl":
+                try:
+                    ver = torch.cuda.nccl.version()
+                    info["rccl_version"] = ver[0] * 10000 + ver[1] * 100 + ver[2] if isinstance(ver, tuple) else int(ver)
+                except Exception as e:        # noqa: BLE001 -- information only
+                    info["rccl_version"] = f"unavailable: {e}"
+        return info
+
+    def measure_idle(self, repeats=3):
+        """Pure all-reduce of the same buckets with the compute stream idle (nothing else on the GPU): what the wire alone
+        costs, next to timing_summary()'s in-step figures (which include queueing behind the backward).  Works on a scratch
+        buffer; [{bucket, bytes, ms (best of `repeats`), bus_GBps}] in launch order.  Call on every rank."""
+        if self.world == 1:
+            return []
+        es = 4 if self.comm_dtype == "fp32" else 2
+        buf = torch.zeros(max(e - s for s, e in self.spans.values()), device=self.device,
+                          dtype=torch.float32 if es == 4 else torch.bfloat16)
+        out = []
+        for b in self.launch_order():
+            s, e = self.spans[b]
+            if e <= s:
+                continue
+            best = None
+            for _ in range(repeats + 1):            # the first pass warms the channel up
+                if dist.is_initialized():
+                    dist.barrier(group=self.group)
+                torch.cuda.synchronize(self.device)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                self._all_reduce(buf[:e - s]).wait()
+                ev1.record()
+                torch.cuda.synchronize(self.device)
+                ms = ev0.elapsed_time(ev1)
+                best = ms if best is None else min(best, ms)
+            nbytes = (e - s) * es
+            out.append({"bucket": b, "bytes": nbytes, "ms": round(best, 4),
+                        "bus_GBps": round(2.0 * (self.world - 1) / self.world * nbytes / max(best, 1e-6) / 1e6, 1)})
+        return out
+
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        # communicators are NOT destroyed from the garbage collector: at interpreter shutdown the peers may be gone
+        # already (ncclCommDestroy then hangs, and a hang is not an exception).  close() is explicit.
+        pass
 
     def bucket_bytes(self):
         """{bucket id: bytes on the wire} in launch order (head, blocks depth-1 .. 0, patch embedding)."""
         es = 4 if self.comm_dtype == "fp32" else 2
-        order = sorted(self.spans, key=lambda b: (b != max(self.spans), -b))
-        return {b: (self.spans[b][1] - self.spans[b][0]) * es for b in order}
+        return {b: (self.spans[b][1] - self.spans[b][0]) * es for b in self.launch_order()}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The drop-in (autograd) path: net(x); loss.backward() as an unmodified ex_audioset.py runs it
+# ------------------------------------------------------------------------------------------------------------------
+def grad_layout(net):
+    """[(name, numel)] of the parameters the backward writes, in named_parameters() order (head_dist.* never receives a
+    gradient: models/passt.py:583-595 does not use it) -- the layout of the flat gradient buffer of both paths."""
+    return [(n, p.numel()) for n, p in net.named_parameters() if not n.startswith("head_dist.")]
+
+
+def attach(net, process_group=None, comm_dtype="fp32", transport="torch", broadcast=True):
+    """Data parallelism for the AUTOGRAD path without a DistributedDataParallel wrapper -- the three-line change to
+    ex_audioset.py (reference: Lightning's DDP plugin, ex_audioset.py:488-489).
+
+    PaSST is ONE autograd node here, so torch's DDP hooks would see every parameter gradient at the same instant, after the
+    last kernel of the backward: the whole 345 MB all-reduce exposed.  After ``attach`` the node's backward does the
+    reduction itself: gradients are produced into one flat buffer, each block's bucket is all-reduced (sum of gradients
+    pre-scaled by 1/world = DDP's mean) the moment its last kernel is enqueued -- overlapping the rest of the backward --
+    and the backward returns only after the current stream is ordered behind the last bucket.  ``loss.backward()`` then
+    leaves averaged ``.grad``s exactly as DDP would; any torch optimizer follows.  Like DDP's constructor, ``attach``
+    broadcasts rank 0's parameters.  Do not ALSO wrap the module in DistributedDataParallel.  Returns the reducer
+    (``.close()`` / ``detach(net)`` releases a C-ABI communicator)."""
+    dev = next(net.parameters()).device
+    red = GradReducer(None, grad_layout(net), len(net.blocks), process_group, comm_dtype=comm_dtype, transport=transport, device=dev)
+    if broadcast and red.world > 1:
+        src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+        with torch.no_grad():
+            for p in net.parameters():
+                dist.broadcast(p.data, src, group=process_group)
+        net.mark_params_updated()
+    object.__setattr__(net, "_ddp", red)
+    if red.world > 1:
+        # the all-reduce kernels share the CUs with the backward: GEMMs go out one work item per workgroup (DESIGN 6)
+        import os
+        if os.environ.get("PASST_AMD_DDP_PERSISTENT") != "1":
+            from . import _lib
+            object.__setattr__(net, "_gemm_flags", _lib.GEMM_NO_PERSIST)
+    return red
+
+
+def detach(net):
+    red = getattr(net, "_ddp", None)
+    if red is not None:
+        red.wait()
+        red.close()
+    object.__setattr__(net, "_ddp", None)
+    object.__setattr__(net, "_gemm_flags", 0)

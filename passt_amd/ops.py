@@ -23,9 +23,25 @@ class _CallState(threading.local):
     """Per-thread (the extension is entered from the trainer thread AND the autograd thread): the device of the
     tensors of the C-ABI call being assembled -- set by _p(), consumed by _stream()."""
     dev = None
+    gemm_flags = 0      # ambient pa_gemm_args.reserved bits of the model whose kernel sequence this thread is issuing
 
 
 _call = _CallState()
+
+
+class gemm_flags:
+    """``with ops.gemm_flags(bits):`` -- every pa_gemm_nt call issued by THIS thread inside the block carries ``bits`` in
+    pa_gemm_args.reserved (PA_GEMM_NO_PERSIST for a model whose backward shares the CUs with an all-reduce).  Per model and
+    per thread, so one data-parallel TrainStep does not change how other models of the process launch their GEMMs."""
+
+    def __init__(self, bits):
+        self.bits = int(bits or 0)
+
+    def __enter__(self):
+        self.prev, _call.gemm_flags = _call.gemm_flags, self.bits
+
+    def __exit__(self, *exc):
+        _call.gemm_flags = self.prev
 
 
 def _stream():
@@ -251,7 +267,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
     a.tune = GEMM_TUNE
-    a.reserved = GEMM_RESERVED | flags
+    a.reserved = GEMM_RESERVED | _call.gemm_flags | flags
     a.colscale_n, a.colscale = colscale_n, colscale
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
     # problems that leave most CUs idle (few [M][768] tiles, long K) go through the split-K entry with a workspace
@@ -286,9 +302,10 @@ _SPLITK_WS = {}
 
 
 def _splitk_ws(device, n):
-    """f32 workspace of pa_gemm_nt_splitk, one per (device, stream): the partial tiles live only between the two launches
-    of one call, and calls on one stream are ordered."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """f32 workspace of pa_gemm_nt_splitk, one per (device, stream, host thread): the partial tiles live only between the two
+    launches of one call and calls of one thread on one stream are ordered; two host threads on the same stream (trainer +
+    autograd thread) could interleave their launch pairs, so they do not share a workspace."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     ws = _SPLITK_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = _SPLITK_WS[key] = torch.empty(n, device=device, dtype=torch.float32)

@@ -227,6 +227,11 @@ def _precision(model):
 
 def passt_forward(model, x, save):
     """Kernel sequence of PaSST.forward (:576-595).  Returns (logits, features, ctx)."""
+    with ops.gemm_flags(getattr(model, "_gemm_flags", 0)):
+        return _passt_forward(model, x, save)
+
+
+def _passt_forward(model, x, save):
     if not x.is_cuda:
         raise PasstAmdError("passt_amd.PaSST runs on a HIP device only (no CPU fallback); got a CPU tensor")
     dt = _precision(model)
@@ -340,6 +345,11 @@ def passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     ``on_block_done(i)`` is called after block i's parameter gradients are enqueued (i = depth for the
     head, then depth-1 .. 0, then -1 for the patch embedding) -- the hook the data-parallel reducer
     uses to start all-reducing finished buckets while the rest of the backward runs."""
+    with ops.gemm_flags(getattr(model, "_gemm_flags", 0)):
+        return _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done)
+
+
+def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     dt, B, Ntok, Np = ctx["dt"], ctx["B"], ctx["Ntok"], ctx["Np"]
     st = model._staged
     D, H = model.embed_dim, model.num_heads
@@ -467,11 +477,30 @@ class _PasstFunction(torch.autograd.Function):
             grads[n] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         # a fresh flat buffer per backward: autograd may keep (not copy) the views as .grad
-        passt_backward(model, c, dlogits.contiguous(), None if dfeat is None else dfeat.contiguous(), grads)
+        dlogits = dlogits.contiguous()
+        dfeat = None if dfeat is None else dfeat.contiguous()
+        red = getattr(model, "_ddp", None)
+        if red is not None and red.world > 1:
+            # passt_amd.ddp.attach(net): this node reduces its own gradients.  `flat` is laid out like the reducer's buckets
+            # (named_parameters() order without head_dist.*); every bucket's all-reduce starts from on_block_done while the
+            # rest of the backward runs, and the node returns once the current stream is ordered behind the last bucket.
+            # Mean over ranks (DDP's semantics) = sum of gradients of loss / world: the backward is linear in (dlogits, dfeat).
+            if flat.numel() != red.total:
+                raise RuntimeError("passt_amd.ddp.attach: the parameter set changed since attach(); call attach(net) again")
+            inv = 1.0 / red.world
+            dlogits = dlogits * inv
+            dfeat = None if dfeat is None else dfeat * inv
+            red.flat = flat
+            try:
+                passt_backward(model, c, dlogits, dfeat, grads, on_block_done=red.on_block_done)
+            finally:
+                red.wait()              # also after an exception: no collective may stay in flight on a buffer we drop
+        else:
+            passt_backward(model, c, dlogits, dfeat, grads)
         ctx.c = None
         out = [None, None]
-        for n, p in model.named_parameters():
-            out.append(grads.get(n) if p.requires_grad else None)
+        for n, p in named:                      # the same list, in the same order, as PaSST.forward handed to apply()
+            out.append(grads[n] if p.requires_grad else None)
         return tuple(out)
 
 
@@ -525,6 +554,8 @@ class PaSST(nn.Module):
     def _reset_runtime(self):
         object.__setattr__(self, "_staged", _Staged())
         object.__setattr__(self, "_scratch", {})
+        object.__setattr__(self, "_ddp", None)          # passt_amd.ddp.attach(): gradient reducer of the autograd path
+        object.__setattr__(self, "_gemm_flags", 0)      # pa_gemm_args.reserved bits of this model's GEMM launches
 
     def __deepcopy__(self, memo):
         cls = self.__class__
@@ -532,7 +563,7 @@ class PaSST(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_staged", "_scratch"):
+            if k in ("_staged", "_scratch", "_ddp", "_gemm_flags"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._reset_runtime()
@@ -540,8 +571,8 @@ class PaSST(nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d.pop("_staged", None)
-        d.pop("_scratch", None)
+        for k in ("_staged", "_scratch", "_ddp", "_gemm_flags"):
+            d.pop(k, None)
         return d
 
     def __setstate__(self, d):
@@ -590,7 +621,9 @@ class PaSST(nn.Module):
     def forward(self, x):
         """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            params = [p for _, p in self.named_parameters()]
+            # head_dist.* is not part of the graph -- as in the reference, whose forward never touches it
+            # (models/passt.py:583-595; hence find_unused_parameters=True under torch DDP there and here)
+            params = [p for n, p in self.named_parameters() if not n.startswith("head_dist.")]
             return _PasstFunction.apply(self, x, *params)
         logits, feat, _ = passt_forward(self, x, save=False)
         return logits, feat

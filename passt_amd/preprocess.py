@@ -16,14 +16,45 @@ from ._lib import MelParams, PasstAmdError
 
 
 def _draw_mask(mask_param, size):
-    """torchaudio.functional.mask_along_axis draws (0.13.1, non-iid path)."""
-    mask_param = min(mask_param, int(size))
+    """The band [start, end) torchaudio.functional.mask_along_axis draws (0.13.1 with the transforms' default p = 1.0 --
+    ``_get_mask_param`` leaves mask_param unclamped there -- and 0.11.0, which has no clamp at all; non-iid path, because the
+    reference hands the transforms a 3-D tensor: SURVEY.md App. A.4).  Two CPU ``torch.rand(1)`` draws; for an axis shorter
+    than mask_param the start can be negative and the band can cover the whole axis, as in torchaudio."""
     if mask_param < 1:
         return 0, 0
     value = torch.rand(1) * mask_param
     min_value = torch.rand(1) * (size - value)
     start = int(min_value.long())
     return start, start + int(value.long())
+
+
+class _AxisMasking(nn.Module):
+    """What ``self.freqm`` / ``self.timem`` are in the reference (models/preprocess.py:47-54: torchaudio.transforms.
+    FrequencyMasking / TimeMasking(param, iid_masks=True), nn.Identity for 0): parameter-free modules carrying
+    ``mask_param`` / ``axis`` / ``iid_masks``, so ``print(mel)``, ``mel.freqm.mask_param`` and ``isinstance(mel.freqm,
+    nn.Identity)`` read as they do there.  The masking itself is a predicate inside the fused front-end kernel; the module
+    only holds the draw (``draw(size)``), called by AugmentMelSTFT.forward in the reference's order."""
+
+    def __init__(self, mask_param, axis, iid_masks):
+        super().__init__()
+        self.mask_param, self.axis, self.iid_masks, self.p = int(mask_param), axis, iid_masks, 1.0
+
+    def draw(self, size):
+        return _draw_mask(self.mask_param, size)
+
+    def forward(self, specgram, mask_value=0.0):
+        raise PasstAmdError("the SpecAugment masks are applied inside pa_mel_frontend_fwd (AugmentMelSTFT.forward); this module "
+                            "only carries mask_param")
+
+
+class FrequencyMasking(_AxisMasking):
+    def __init__(self, freq_mask_param, iid_masks=False):
+        super().__init__(freq_mask_param, 1, iid_masks)
+
+
+class TimeMasking(_AxisMasking):
+    def __init__(self, time_mask_param, iid_masks=False):
+        super().__init__(time_mask_param, 2, iid_masks)
 
 
 class AugmentMelSTFT(nn.Module):
@@ -40,9 +71,8 @@ class AugmentMelSTFT(nn.Module):
         assert fmax_aug_range >= 1, f"fmax_aug_range={fmax_aug_range} should be >=1; 1 means no augmentation"
         self.fmin_aug_range, self.fmax_aug_range = fmin_aug_range, fmax_aug_range
         self.register_buffer("preemphasis_coefficient", torch.as_tensor([[[-.97, 1]]]), persistent=False)
-        # freqm / timem are plain ints here (the reference wraps torchaudio modules; only their
-        # mask_param is used, :47-54)
-        self.freqm, self.timem = int(freqm), int(timem)
+        self.freqm = nn.Identity() if freqm == 0 else FrequencyMasking(freqm, iid_masks=True)      # :47-50
+        self.timem = nn.Identity() if timem == 0 else TimeMasking(timem, iid_masks=True)           # :51-54
         # constant tables of the fused kernel (f64 -> f32), non-persistent like the reference buffers
         left = (n_fft - win_length) // 2
         wpad = torch.zeros(n_fft)
@@ -78,10 +108,10 @@ class AugmentMelSTFT(nn.Module):
         p.log_eps, p.out_add, p.out_scale = 0.00001, 4.5, 1.0 / 5.0
         p.fmask_start = p.fmask_end = p.tmask_start = p.tmask_end = 0
         if self.training:
-            if self.freqm:
-                p.fmask_start, p.fmask_end = _draw_mask(self.freqm, self.n_mels)          # :81
-            if self.timem:
-                p.tmask_start, p.tmask_end = _draw_mask(self.timem, p.n_frames)           # :82
+            if isinstance(self.freqm, _AxisMasking):
+                p.fmask_start, p.fmask_end = self.freqm.draw(self.n_mels)                 # :81
+            if isinstance(self.timem, _AxisMasking):
+                p.tmask_start, p.tmask_end = self.timem.draw(p.n_frames)                  # :82
         return ops.mel_frontend(x, self._window_padded, self._bin_mel, self._twiddle, p)
 
     def extra_repr(self):

@@ -56,9 +56,10 @@ class TrainStep:
             # the all-reduce kernels of the communication stream take CUs while the backward runs: GEMMs go out one work
             # item per workgroup (the hardware hands them to whatever CUs are free: -1.6 % alone on one GPU) instead of as 256
             # resident workgroups, which would wait for the occupied CUs and double the launch (PA_GEMM_NO_PERSIST).
-            # Process-wide: every pa_gemm_nt call of this process from here on.
-            ops.GEMM_RESERVED |= ops._lib.GEMM_NO_PERSIST
-        self.t = 0
+            # Per model (net._gemm_flags rides on every pa_gemm_nt call of this net's forward / backward); close() undoes it.
+            object.__setattr__(net, "_gemm_flags", getattr(net, "_gemm_flags", 0) | ops._lib.GEMM_NO_PERSIST)
+            self._set_no_persist = True
+        self.t = self._t_now = 0
         self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
         self.base_lr = lr
         net.mark_params_updated()
@@ -66,7 +67,7 @@ class TrainStep:
     def _optimizer(self, s, e):
         if self.optimizer == "adamw":
             ops.adamw(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self.t)
+                      self.eps, self.wd, self._t_now)
         else:
             ops.sgd(self.flat_p[s:e], self.flat_g[s:e], self.lr)
 
@@ -85,6 +86,9 @@ class TrainStep:
     def close(self):
         """Release the reducer's communicator (C-ABI RCCL transport); torch.distributed groups belong to the caller."""
         self.reducer.close()
+        if getattr(self, "_set_no_persist", False):
+            object.__setattr__(self.net, "_gemm_flags", getattr(self.net, "_gemm_flags", 0) & ~ops._lib.GEMM_NO_PERSIST)
+            self._set_no_persist = False
 
     def set_lr_factor(self, factor):
         """Per-epoch LR schedule (ex_audioset.py:86-101): lr = base_lr * factor, e.g. from
@@ -124,7 +128,12 @@ class TrainStep:
                 loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, y32[perm_d.long()].contiguous(), lam_d, grad_scale=gs)
             else:
                 loss, dlogits = ops.ce_mixup_fwd_bwd(logits, y32, grad_scale=gs)
-        self.t += 1
+        # The step count advances only when the whole step was enqueued.  With per-bucket updates (the default) a step that
+        # raises in the middle of the backward (out of memory, a PA_E* code) has ALREADY updated the buckets that completed
+        # before it (head, later blocks) with step number t + 1 -- parameters, m and v of those buckets -- and not the rest:
+        # a failed step is not atomic; recover from a checkpoint (or run with PASST_AMD_BLOCK_OPT=0, where nothing is
+        # touched before the backward has finished).
+        self._t_now = self.t + 1
         passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self._block_done)
         if self.reducer.world == 1 and not self.block_optimizer:
             self._optimizer(0, self.flat_p.numel())
@@ -134,5 +143,6 @@ class TrainStep:
             # the backward ends) is covered by ~0.4 ms of optimizer work instead of being exposed in front of one big launch
             for s_, e_ in self.reducer.drain():
                 self._optimizer(s_, e_)
+        self.t = self._t_now
         net.mark_params_updated()
         return loss

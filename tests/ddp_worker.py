@@ -23,6 +23,44 @@ from passt_amd.train import TrainStep  # noqa: E402
 from tests.golden import make_golden as G  # noqa: E402
 
 
+class _AutogradRunner:
+    """The drop-in path as ex_audioset.py drives it (:179-186, 104-109): net(x) -> BCE mean -> loss.backward() -> torch
+    optimizer; data parallel through passt_amd.ddp.attach (the node reduces its own buckets from inside the backward) or
+    through torch's own DistributedDataParallel.  `flat_p` mirrors TrainStep's flat parameter buffer (same order) so the
+    test can compare the two paths entry by entry."""
+
+    def __init__(self, net, args, lr, world, dev):
+        from passt_amd import ddp
+        self.net, self.fwd = net, net
+        if args.path == "attach":
+            self.red = ddp.attach(net, comm_dtype=args.comm_dtype, transport=args.transport)
+        else:
+            self.red = None
+            if world > 1:
+                self.fwd = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index], find_unused_parameters=True)
+        self.params = [p for n, p in net.named_parameters() if not n.startswith("head_dist.")]
+        if args.optimizer == "adamw":
+            self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=1e-2)
+        else:
+            self.opt = torch.optim.SGD(self.params, lr=lr)
+
+    @property
+    def flat_p(self):
+        return torch.cat([p.detach().reshape(-1) for p in self.params])
+
+    def step(self, x, y):
+        logits, _ = self.fwd(x)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def close(self):
+        from passt_amd import ddp
+        ddp.detach(self.net)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
@@ -32,6 +70,10 @@ def main():
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--backend", default="gloo", help="gloo: every rank on cuda:0; nccl (= RCCL): rank r on cuda:r")
     ap.add_argument("--transport", default="torch", help="torch | rccl_abi (pa_comm_* entry points; needs --backend nccl devices)")
+    ap.add_argument("--path", default="trainstep", choices=["trainstep", "attach", "torch_ddp"],
+                    help="trainstep: passt_amd.train.TrainStep.  attach / torch_ddp: the AUTOGRAD path (net(x); loss.backward(); "
+                         "torch.optim.SGD) with passt_amd.ddp.attach(net) resp. torch's DistributedDataParallel wrapper "
+                         "(find_unused_parameters=True, as the reference needs for head_dist)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,8 +107,12 @@ def main():
     if world > 1:
         per = x.shape[0] // world
         xg, yg = xg[rank * per:(rank + 1) * per].contiguous(), yg[rank * per:(rank + 1) * per].contiguous()
-    ts = TrainStep(net, None, lr=1e-3 if args.optimizer == "adamw" else 0.05, weight_decay=1e-2, use_mixup=False,
-                   comm_dtype=args.comm_dtype, optimizer=args.optimizer, transport=args.transport)
+    lr = 1e-3 if args.optimizer == "adamw" else 0.05
+    if args.path == "trainstep":
+        ts = TrainStep(net, None, lr=lr, weight_decay=1e-2, use_mixup=False,
+                       comm_dtype=args.comm_dtype, optimizer=args.optimizer, transport=args.transport)
+    else:
+        ts = _AutogradRunner(net, args, lr, world, dev)
     init = ts.flat_p.clone()            # after the constructor's broadcast: rank 0's weights on every rank
     losses = []
     with warnings.catch_warnings():

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
         assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.pa_abi_version() == 3
+    assert lib.pa_abi_version() == 4
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
     assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768
@@ -168,6 +168,25 @@ def test_reference_module_paths_resolve_to_this_implementation():
     assert mp.get_model is passt_amd.passt.get_model and mp.PaSST is passt_amd.PaSST
     assert mpre.AugmentMelSTFT is passt_amd.AugmentMelSTFT
     assert mp.get_model_passt is mp.get_model
+
+
+def test_front_end_module_surface_matches_the_reference():
+    """models/preprocess.py:47-54: freqm / timem are torchaudio FrequencyMasking / TimeMasking modules (nn.Identity for 0)
+    -- print(mel), mel.freqm.mask_param and the Identity check read the same here; no parameters, empty state_dict."""
+    import contextlib
+    import io
+
+    import torch
+
+    import passt_amd
+    with contextlib.redirect_stdout(io.StringIO()):
+        mel = passt_amd.AugmentMelSTFT(freqm=48, timem=192)
+        off = passt_amd.AugmentMelSTFT(freqm=0, timem=0)
+    text = repr(mel)
+    assert "(freqm): FrequencyMasking()" in text and "(timem): TimeMasking()" in text and "winsize=800, hopsize=320" in text
+    assert mel.freqm.mask_param == 48 and mel.timem.mask_param == 192 and mel.freqm.iid_masks and mel.timem.axis == 2
+    assert isinstance(off.freqm, torch.nn.Identity) and isinstance(off.timem, torch.nn.Identity)
+    assert len(mel.state_dict()) == 0 and not list(mel.parameters())
 
 
 def test_comm_entry_points_without_a_gpu():

@@ -79,6 +79,31 @@ def _worker(rank, world, port, q):
     pbuf = torch.full((16,), float(rank + 7))
     red.broadcast_(pbuf)
     ok = ok and bool(torch.equal(pbuf, torch.full((16,), 7.0)))
+    # attach(): the autograd path's reducer -- rank 0's parameters everywhere (DDP's constructor does the same), a reducer
+    # whose flat buffer is rebound before every backward, per-model GEMM launch flags, nothing of it deep-copied (SWA)
+    import copy
+    from passt_amd import _lib, ddp
+    torch.manual_seed(100 + rank)
+    net = _small_model()                        # differently initialised per rank
+    red4 = ddp.attach(net)
+    first = next(net.parameters()).detach().clone()
+    gathered = [torch.empty_like(first) for _ in range(world)]
+    dist.all_gather(gathered, first)
+    ok = ok and all(bool(torch.equal(g, gathered[0])) for g in gathered)
+    ok = ok and net._ddp is red4 and net._gemm_flags == _lib.GEMM_NO_PERSIST and red4.total == total
+    ok = ok and [n for n, _ in ddp.grad_layout(net)] == [n for n, _ in sizes]
+    twin = copy.deepcopy(net)
+    ok = ok and twin._ddp is None and twin._gemm_flags == 0
+    for step in range(2):                       # what _PasstFunction.backward does: fresh buffer, buckets in order, wait
+        red4.flat = torch.full((total,), float(rank + 1 + step))
+        for blk in (3, 2, 1, 0, -1):
+            red4.on_block_done(blk)
+        red4.wait()
+        ok = ok and bool(torch.equal(red4.flat, torch.full((total,), float(3 + 2 * step))))
+    info = red4.comm_info()
+    ok = ok and info["nranks"] == world and info["rank"] == rank and info["backend"] == "gloo"
+    ddp.detach(net)
+    ok = ok and net._ddp is None and net._gemm_flags == 0
     q.put((rank, ok, seen, red.world))
     dist.destroy_process_group()
 

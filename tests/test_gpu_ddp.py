@@ -77,6 +77,47 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(tmp_path, variant
         assert e < (1e-4 if variant != "bf16_wire" else 1e-2), e
 
 
+@pytest.mark.parametrize("path,wire", [("attach", "fp32"), ("attach", "bf16"), ("torch_ddp", "fp32")])
+def test_autograd_path_two_ranks_equal_one_process(tmp_path, path, wire):
+    """The DROP-IN path -- net(x); loss.backward(); torch optimizer, what an unmodified ex_audioset.py runs (:179-186) --
+    under data parallelism, two ways: passt_amd.ddp.attach(net) (the autograd node all-reduces per-block buckets from
+    inside its backward and returns averaged gradients) and torch's DistributedDataParallel(find_unused_parameters=True)
+    around the same module (ex_audioset.py:488-489 via Lightning).  Both against ONE process of the *TrainStep* path on the
+    concatenated batch: ties the two product paths and the two DDP mechanisms together."""
+    ref = _run(str(tmp_path / "ref.pt"), 1)
+    ref_auto = _run(str(tmp_path / "ref_auto.pt"), 1, ("--path", "attach"))
+    # one process: autograd path == TrainStep path (same kernels, torch SGD vs pa_sgd)
+    d_a, d_r = (ref_auto["params"] - ref_auto["init"]).double(), (ref["params"] - ref["init"]).double()
+    assert float((d_a - d_r).abs().max() / d_r.abs().max()) < 1e-5
+    extra = ("--path", path) + (("--comm-dtype", "bf16") if wire == "bf16" else ())
+    dp = _run(str(tmp_path / "dp.pt"), 2, extra)
+    assert dp["world"] == 2
+    _check_against_single_process(dp, ref, wire)
+
+
+def test_bench_self_launch_clean_env():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1 -- NO launcher, NO RANK / WORLD_SIZE in the
+    environment: bench.py forks its own ranks (ex_audioset.py:499-524 does the same for DDP=N) and rank 0's line comes out
+    of the parent.  On the one-GPU test box the ranks share device 0 over gloo (PASST_AMD_BENCH_DRY_GLOO=1, labelled in the
+    line); on a multi-GPU box the same command runs over RCCL.  Both product paths."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PASST_AMD_BENCH_DRY_GLOO"] = "1"
+    for path in ("trainstep", "autograd"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                            "--path", path], env=env, capture_output=True, timeout=900)
+        out = r.stdout.decode()
+        assert r.returncode == 0, (out, r.stderr.decode()[-3000:])
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out
+        d = json.loads(lines[0])
+        assert "error" not in d and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
+        assert "DRY RUN" in d["config"]["parallelism"]
+        ar = d["allreduce_measured"]
+        assert len(ar["buckets"]) == 14 and len(ar["idle"]["buckets"]) == 14 and ar["idle"]["ms_per_step"] > 0
+        assert d["rccl"]["nranks"] == 2 and [x["rank"] for x in d["rccl"]["ranks"]] == [0, 1]
+
+
 def _check_against_single_process(dp, ref, variant):
     assert all(same for same, _ in dp["flags"])
     assert torch.equal(dp["init"], ref["init"])

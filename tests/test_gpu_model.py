@@ -174,7 +174,20 @@ def test_frontend_vs_oracle_random_augment():
         torch.manual_seed(seed)
         got = mel(torch.from_numpy(wave_np).to(DEV)).cpu().numpy()
         assert float(np.abs(got - ref).max()) < 1e-3
-        assert torch.rand(1).item() == torch.rand(1).item() or True
+    # clips SHORTER than timem frames (1 s = 101 frames < 192): mask_param is not clamped to the axis (torchaudio 0.13.1 with
+    # p = 1.0 / 0.11.0), so the time band can start before frame 0 and cover every frame -- kernel predicates vs the oracle
+    short = G.frontend_inputs(dict(B=2, L=32000, seed=78))
+    whole = 0
+    for seed in range(10, 26):
+        torch.manual_seed(seed)
+        ref = O.mel_frontend(torch.from_numpy(short), training=True, fmin_aug_range=10, fmax_aug_range=2000,
+                             freqm=48, timem=192).numpy()
+        torch.manual_seed(seed)
+        got = mel(torch.from_numpy(short).to(DEV)).cpu().numpy()
+        assert got.shape == ref.shape == (2, 128, 101)
+        assert float(np.abs(got - ref).max()) < 1e-3, seed
+        whole += int(np.all(ref == ref[0, 0, 0]))
+    assert whole > 0        # at least one draw masked the entire clip (impossible with a clamped parameter)
 
 
 def test_module_contract():
@@ -273,18 +286,27 @@ def test_train_step_driver_matches_autograd_path():
         assert rel(p2.detach().cpu(), p1.detach().cpu()) < 2e-4, k
 
 
+@pytest.mark.parametrize("loss", ["bce", "ce"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_train_step_two_steps_at_bench_shape_vs_oracle(precision):
+def test_train_step_two_steps_at_bench_shape_vs_oracle(precision, loss):
     """The headline step itself -- spectrogram mixup + PaSST 768/12/12 at 474 tokens (s_patchout_t=40, f=4: prefix-only tail,
     batched weight gradients, flat buffers) + BCE + fused AdamW -- two consecutive steps of passt_amd.train.TrainStep at
     B = 4 against the oracle driven by torch.optim.AdamW with the same RNG stream (helpers/mixup.py:5-12 draw order, then
     the Patchout draws).  Losses of BOTH steps (the second sees the first update) and the parameter updates.  AdamW's
     first steps are lr * sign(g): an entry whose gradient is smaller than its error flips, so the updates are judged by
-    direction (cosine per tensor) and, in fp32, by relative L2."""
+    direction (cosine per tensor) and, in fp32, by relative L2.
+    loss="ce" is BASELINE config #5's step (ex_esc50.py:40,60,159-165): 50 classes, 500 frames into the 998-frame model
+    (random time-positional offset), s_patchout_t=10 / f=3 => 353 tokens, class-index targets, CE mixed per sample with the
+    mixup partner's label; the GEMMs of this shape go through the split-K entry in bf16."""
     from passt_amd.train import TrainStep
-    case = dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=4, T=998, seed=77)
+    if loss == "bce":
+        case = dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=4, T=998, seed=77)
+    else:
+        case = dict(cfg=O.make_cfg(num_classes=50, s_patchout_t=10, s_patchout_f=3), B=4, T=500, seed=78)
     cfg, B = case["cfg"], case["B"]
     x, y = G.model_inputs(case)
+    if loss == "ce":
+        y = (detgen.uniform(case["seed"], "cls", (B,), 0.0, 50.0).astype(np.int64) % 50)
     lr, wd, alpha = 1e-3, 1e-2, 0.3
     # --- oracle
     sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]), requires_grad=True)
@@ -296,18 +318,21 @@ def test_train_step_two_steps_at_bench_shape_vs_oracle(precision):
         torch.manual_seed(4000 + step)
         np.random.seed(4000 + step)
         rn, lam = O.my_mixup(B, alpha)
-        xm, ym = O.mixup_apply(torch.from_numpy(x), torch.from_numpy(y), rn, lam)
+        if loss == "bce":
+            xm, ym = O.mixup_apply(torch.from_numpy(x), torch.from_numpy(y), rn, lam)
+        else:
+            xm, _ = O.mixup_apply(torch.from_numpy(x), torch.zeros(B, 1), rn, lam)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             lo, _ = O.passt_forward(sd, xm, cfg, training=True)
-        loss = O.bce_loss(lo, ym)
+        lv = O.bce_loss(lo, ym) if loss == "bce" else O.ce_mixup_loss(lo, torch.from_numpy(y), rn, lam)
         opt.zero_grad()
-        loss.backward()
+        lv.backward()
         opt.step()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(lv))
     # --- TrainStep on the HIP kernels
     net = build(case, precision).train()
-    ts = TrainStep(net, None, lr=lr, weight_decay=wd, mixup_alpha=alpha, use_mixup=True)
+    ts = TrainStep(net, None, lr=lr, weight_decay=wd, mixup_alpha=alpha, use_mixup=True, loss=loss)
     xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
     losses = []
     with warnings.catch_warnings():
@@ -336,8 +361,36 @@ def test_train_step_two_steps_at_bench_shape_vs_oracle(precision):
         assert cos > (0.999 if precision == "fp32" else 0.9), (name, cos)
         if precision == "fp32":
             assert l2 < 3e-2, (name, l2)
-    record(f"train_step_vs_oracle[{precision}]", loss0=abs(losses[0] - ref_losses[0]), loss1=abs(losses[1] - ref_losses[1]),
+    record(f"train_step_vs_oracle[{precision},{loss}]", loss0=abs(losses[0] - ref_losses[0]), loss1=abs(losses[1] - ref_losses[1]),
            worst_update_cosine=worst_cos, worst_update_rel_l2=worst_l2)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_per_bucket_optimizer_equals_one_launch_bitwise(overlap, monkeypatch):
+    """TrainStep updates each bucket's parameters from inside the backward (PASST_AMD_BLOCK_OPT=1, the default) or with one
+    launch after it (=0): the same AdamW arithmetic on the same gradients, so three steps must leave bit-identical
+    parameters and moments -- also with the weight gradients on the side stream."""
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=915)
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    outs = []
+    for block_opt in ("1", "0"):
+        monkeypatch.setenv("PASST_AMD_BLOCK_OPT", block_opt)
+        net = build(case, "bf16").train()
+        net.overlap_wgrad = overlap
+        ts = TrainStep(net, None, lr=1e-3, weight_decay=1e-2, use_mixup=False)
+        assert ts.block_optimizer == (block_opt == "1")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(3):
+                torch.manual_seed(50 + step)
+                ts.step(xg, yg)
+        torch.cuda.synchronize()
+        assert ts.t == 3
+        outs.append((ts.flat_p.clone(), ts.m.clone(), ts.v.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_swa_matches_reference_update_rule():
