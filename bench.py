@@ -200,6 +200,8 @@ class AutogradStep:
         from passt_amd import ddp
         self.net, self.mel, self.loss, self.alpha = net, mel, loss, mixup_alpha
         self.autocast = precision == "bf16"
+        self.phases = {} if os.environ.get("PASST_AMD_BENCH_PHASES") == "1" else None
+        self._mark = None
         net.precision = None                    # follow torch.autocast, like the reference under Lightning AMP
         self.reducer = ddp.attach(net, comm_dtype=comm_dtype, transport=transport)
         if optimizer == "adamw":
@@ -208,33 +210,65 @@ class AutogradStep:
             self.opt = torch.optim.SGD(net.parameters(), lr=lr)
 
     def step(self, x, y):
+        if self.phases is not None:
+            return self._step_phases(x, y)
+        return self._step(x, y)
+
+    def _step_phases(self, x, y):
+        """PASST_AMD_BENCH_PHASES=1: the same step with a device synchronize between its phases (diagnostic; not a bench mode)"""
+        marks = []
+
+        def mark(name):
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+        self._mark = mark
+        mark("start")
+        out = self._step(x, y)
+        mark("optimizer")
+        for (_, t0), (n, t1) in zip(marks, marks[1:]):
+            self.phases[n] = self.phases.get(n, 0.0) + (t1 - t0)
+        self.phases["steps"] = self.phases.get("steps", 0) + 1
+        self._mark = None
+        return out
+
+    def _step(self, x, y):
         F = torch.nn.functional
         net = self.net
+        mark = self._mark or (lambda name: None)
         if self.mel is not None:
             old_shape = x.size()
             x = self.mel(x.reshape(-1, old_shape[2]))
             x = x.reshape(old_shape[0], old_shape[1], x.shape[1], x.shape[2])
+        mark("mel")
         B = len(y)
         perm = torch.randperm(B)
         lam = np.random.beta(self.alpha, self.alpha, B).astype(np.float32)
         lam = torch.from_numpy(np.maximum(lam, 1.0 - lam)).to(x.device)
         x = x * lam.reshape(B, 1, 1, 1) + x[perm] * (1.0 - lam.reshape(B, 1, 1, 1))
+        mark("mixup")
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             y_hat, _ = net(x)
+            mark("forward")
             if self.loss == "bce":
                 y_mix = y * lam.reshape(B, 1) + y[perm] * (1.0 - lam.reshape(B, 1))
                 loss = F.binary_cross_entropy_with_logits(y_hat, y_mix, reduction="none").mean()
             else:
                 sl = F.cross_entropy(y_hat, y, reduction="none") * lam + F.cross_entropy(y_hat, y[perm], reduction="none") * (1.0 - lam)
                 loss = sl.mean()
+        mark("loss")
         self.opt.zero_grad()
         loss.backward()
+        mark("backward")
         self.opt.step()
         return loss.detach()
 
     def close(self):
         from passt_amd import ddp
         ddp.detach(self.net)
+        if self.phases:
+            n = max(self.phases.pop("steps", 1), 1)
+            print("autograd step phases (ms, device synchronised between them): "
+                  + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in self.phases.items()), file=sys.stderr, flush=True)
 
 
 def error_line(args, msg, **extra):

@@ -65,6 +65,89 @@ __global__ __launch_bounds__(512) void k(const bf16x8* __restrict__ ops, float* 
     if (s == 12345.678f) out[0] = s;       // keep the loops alive
 }
 
+// ---- round 4: the same question in CYCLES -----------------------------------------------------------------------------
+// The wall-clock table above cannot tell issue contention from clock droop (the chip is power limited: MFMA-heavy code runs
+// at ~1.6 GHz, VALU-only code near 2.4), and its V wave ran the same number of iterations as the M wave, i.e. it was gone
+// after a third of the M wave's lifetime.  Here the partner wave keeps issuing VALU work for as long as the M wave runs
+// (twice the iteration count), the M wave brackets its loop with s_memtime (shader-clock counter) and s_memrealtime (constant
+// 100 MHz): cycles per iteration say whether the VALU stream takes issue slots from the MFMA stream, and the ratio of the two
+// counters is the clock each combination ran at.  ROLE_B: 0 none, 2 v_fma, 4 v_exp, 5 v_pk_fma (packed).
+template <int ROLE_B>
+__global__ __launch_bounds__(512) void kc(const bf16x8* __restrict__ ops, float* out, unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float c0 = out[1], c1 = out[2];
+    float s = 0.f;
+    if (wave < 4) {
+        bf16x8 a[4], b[2];
+        for (int i = 0; i < 4; ++i) a[i] = ops[(i * 64 + lane) & 1023];
+        for (int j = 0; j < 2; ++j) b[j] = ops[((4 + j) * 64 + lane) & 1023];
+        f32x16 acc[8];
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();         // shader clock
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) s += acc[i][r];
+        asm volatile("s_nop 0" :: "v"(s));
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { cyc[(blockIdx.x * 4 + wave) * 2] = t1 - t0; cyc[(blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0; }
+    } else {
+        if (ROLE_B == 0) return;
+        float v[40];
+        for (int i = 0; i < 40; ++i) v[i] = (float)(lane + i) * 1e-3f;
+        // the M waves run `iters` iterations of >= 256 cycles; 40 VALU are <= 160 cycles, so 2 * iters VALU iterations
+        // outlast them
+        for (int it = 0; it < 2 * iters; ++it) {
+            if (ROLE_B == 2) {
+#pragma unroll
+                for (int i = 0; i < 40; ++i) v[i] = __builtin_fmaf(v[i], c0, c1);
+            } else if (ROLE_B == 4) {
+#pragma unroll
+                for (int i = 0; i < 40; ++i) v[i] = __builtin_amdgcn_exp2f(v[i]);
+            } else {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int i = 0; i < 40; i += 2) {
+                    f32x2 x = {v[i], v[i + 1]};
+                    const f32x2 m = {c0, c0}, a2 = {c1, c1};
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(m), "v"(a2));
+                    v[i] = x[0]; v[i + 1] = x[1];
+                }
+            }
+        }
+        for (int i = 0; i < 40; ++i) s += v[i];
+    }
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int B> static void run_cycles(const char* name, int nwg, const bf16x8* dops, float* dout, unsigned long long* dcyc) {
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    double cyc_best = 0, real_best = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((kc<B>), dim3(nwg), dim3(512), 0, 0, dops, dout, dcyc, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        static unsigned long long h[2048];
+        CK(hipMemcpy(h, dcyc, sizeof(unsigned long long) * nwg * 8, hipMemcpyDeviceToHost));
+        double sum = 0, rsum = 0;
+        for (int i = 0; i < nwg * 4; ++i) { sum += (double)h[2 * i]; rsum += (double)h[2 * i + 1]; }
+        if (ms < best) { best = ms; cyc_best = sum / (nwg * 4) / iters; real_best = rsum / (nwg * 4) / iters; }
+    }
+    // s_memrealtime ticks at 100 MHz: ns = ticks * 10; clock = shader ticks / ns
+    printf("%-24s %4d workgroups: %7.1f shader-clock ticks per 8 MFMA (%5.2f per MFMA), %6.1f ns per 8 MFMA => %.2f GHz; launch %7.3f ms\n",
+           name, nwg, cyc_best, cyc_best / 8, real_best * 10.0, cyc_best / (real_best * 10.0), best);
+}
+
 template <int A, int B> static float run(const char* name, const bf16x8* dops, float* dout) {
     const int iters = 20000;
     hipEvent_t e0, e1;
@@ -103,5 +186,14 @@ int main() {
     run<1, 4>("M + V(exp) on one SIMD (two waves)", dops, dout);
     run<3, 0>("X: one wave, 1 MFMA : 5 FMA interleaved", dops, dout);
     run<3, 3>("X + X on one SIMD", dops, dout);
+    unsigned long long* dcyc;
+    CK(hipMalloc(&dcyc, 2048 * sizeof(unsigned long long)));
+    printf("\n-- cycles (s_memtime) of the MFMA wave while a partner wave on the same SIMD issues VALU work for its whole lifetime --\n");
+    for (int nwg : {8, 256}) {
+        run_cycles<0>("M alone", nwg, dops, dout, dcyc);
+        run_cycles<2>("M + V(v_fma_f32)", nwg, dops, dout, dcyc);
+        run_cycles<5>("M + V(v_pk_fma_f32)", nwg, dops, dout, dcyc);
+        run_cycles<4>("M + V(v_exp_f32)", nwg, dops, dout, dcyc);
+    }
     return 0;
 }
