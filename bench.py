@@ -205,7 +205,10 @@ class AutogradStep:
         net.precision = None                    # follow torch.autocast, like the reference under Lightning AMP
         self.reducer = ddp.attach(net, comm_dtype=comm_dtype, transport=transport)
         if optimizer == "adamw":
-            self.opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=weight_decay)
+            self.opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=weight_decay)       # ex_audioset.py:108, as is
+        elif optimizer == "pa_adamw":
+            from passt_amd import optim as pa_optim                                                 # the one-word change
+            self.opt = pa_optim.AdamW(net.parameters(), lr=lr, weight_decay=weight_decay)
         else:
             self.opt = torch.optim.SGD(net.parameters(), lr=lr)
 
@@ -350,7 +353,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events (measures their cost)")
     ap.add_argument("--no-mel", action="store_true", help="feed spectrograms (reference model_speed_test style)")
-    ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sgd"])
+    ap.add_argument("--optimizer", default="adamw", choices=["adamw", "sgd", "pa_adamw"],
+                    help="adamw: TrainStep's fused pa_adamw resp. (--path autograd) torch.optim.AdamW exactly as ex_audioset.py:108 builds "
+                         "it; pa_adamw (autograd path only): passt_amd.optim.AdamW, the same update as one fused launch")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient kernels on a second stream, one launch per problem (A/B only: since the batched "
                          "per-block launch it measures the same as the default, profiles/r03_finish_stream_experiment.txt)")
@@ -380,6 +385,8 @@ def main():
 
 
 def run(args):
+    if args.optimizer == "pa_adamw" and args.path != "autograd":
+        raise ValueError("--optimizer pa_adamw is the autograd path's fused optimizer; TrainStep's adamw already is the fused kernel")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # dry run of the N > 1 code path on a box with ONE GPU (tests/test_gpu_ddp.py::test_bench_multi_rank_dry_run): every rank
@@ -450,6 +457,8 @@ def run(args):
         for _ in range(args.warmup):
             ts.step(x, y)
         barrier()
+        if getattr(ts, "phases", None) is not None:
+            ts.phases.clear()                   # phase diagnostics: timed steps only (warm-up carries one-time module loads)
         # per-launch HIP events on the GEMM family (roofline): two event records per launch cost ~3.4 % of the step
         # when every step is instrumented, so one timed step in PROFILE_EVERY carries them (always including step 0)
         prof = {} if (rank == 0 and not args.no_roofline) else None
@@ -529,7 +538,8 @@ def run(args):
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
                        "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW)" if args.path == "trainstep" else
                                 "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
-                                + ("AdamW" if args.optimizer == "adamw" else "SGD") + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
+                                + {"adamw": "AdamW (multi-tensor default)", "sgd": "SGD", "pa_adamw": "AdamW replaced by passt_amd.optim.AdamW"}[args.optimizer]
+                                + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
                        "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
                                        if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
                        "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},

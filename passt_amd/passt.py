@@ -460,6 +460,7 @@ class _PasstFunction(torch.autograd.Function):
                                       "training never asks for one); detach() the input")
         logits, feat, c = passt_forward(model, x, save=True)
         ctx.model, ctx.c = model, c
+        ctx.set_materialize_grads(False)        # an unused `features` output arrives as None, not as a zero tensor
         return logits, feat
 
     @staticmethod
@@ -470,13 +471,15 @@ class _PasstFunction(torch.autograd.Function):
                                "pass (retain_graph / double backward are not supported: run the forward again)")
         # gradient buffers for EVERY parameter the backward writes (all but head_dist.*): the kernel sequence produces
         # them all; parameters with requires_grad=False are simply not handed back to autograd (frozen backbone, ...)
-        named = [(n, p) for n, p in model.named_parameters() if not n.startswith("head_dist.")]
-        flat = torch.empty(sum(p.numel() for _, p in named), device=dlogits.device, dtype=torch.float32)
-        grads, off = {}, 0
-        for n, p in named:
-            grads[n] = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
+        named, total = model._graph_params()
+        flat = torch.empty(total, device=dlogits.device, dtype=torch.float32)
+        # one C++ call makes the 159 views (a Python loop of slice + view costs 1.3 ms of host time in front of the first
+        # backward kernel: exposed whenever the caller synchronised in this step, and the reference's mixup does)
+        views = torch._C._nn.unflatten_dense_tensors(flat, [p for _, p in named])
+        grads = {n: v for (n, _), v in zip(named, views)}
         # a fresh flat buffer per backward: autograd may keep (not copy) the views as .grad
+        if dlogits is None:                     # only `features` fed the loss
+            dlogits = torch.zeros((c["B"], model.num_classes), device=flat.device, dtype=torch.float32)
         dlogits = dlogits.contiguous()
         dfeat = None if dfeat is None else dfeat.contiguous()
         red = getattr(model, "_ddp", None)
@@ -579,6 +582,28 @@ class PaSST(nn.Module):
         self.__dict__.update(d)
         self._reset_runtime()
 
+    def _graph_params(self):
+        """([(name, parameter)] without head_dist.*, total numel): what the autograd node takes and returns gradients for, in
+        named_parameters() order.  Cached (walking the module tree costs 0.4 ms per call, twice per step); dropped whenever a
+        parameter or sub-module is assigned on this module or the module is moved / cast (``_apply``).  After surgery deeper
+        in the tree (replacing a sub-module of a block) call ``model._reset_runtime()``."""
+        hit = self._scratch.get("graph_params")
+        if hit is None:
+            named = [(n, p) for n, p in self.named_parameters() if not n.startswith("head_dist.")]
+            hit = self._scratch["graph_params"] = (named, sum(p.numel() for _, p in named))
+        return hit
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)) and "_scratch" in self.__dict__:
+            self._scratch.pop("graph_params", None)
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if "_scratch" in self.__dict__:
+            self._scratch.pop("graph_params", None)
+        return out
+
     @property
     def _grad_names(self):
         return {n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("head_dist.")}
@@ -623,8 +648,7 @@ class PaSST(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # head_dist.* is not part of the graph -- as in the reference, whose forward never touches it
             # (models/passt.py:583-595; hence find_unused_parameters=True under torch DDP there and here)
-            params = [p for n, p in self.named_parameters() if not n.startswith("head_dist.")]
-            return _PasstFunction.apply(self, x, *params)
+            return _PasstFunction.apply(self, x, *[p for _, p in self._graph_params()[0]])
         logits, feat, _ = passt_forward(self, x, save=False)
         return logits, feat
 

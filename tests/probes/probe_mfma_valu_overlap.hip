@@ -124,6 +124,80 @@ __global__ __launch_bounds__(512) void kc(const bf16x8* __restrict__ ops, float*
     if (s == 12345.678f) out[0] = s;
 }
 
+// ---- and the converse: how fast does the VALU wave run while its SIMD partner issues MFMAs back to back? ----------------
+// V waves run `iters` iterations of 40 v_fma and clock themselves; the M partner runs 4x as many MFMA iterations (it outlasts
+// them).  PRIO_M / PRIO_V: s_setprio of the two roles.  If the arbiter served the VALU stream in the issue slots an 8-pass
+// MFMA leaves free (28 of 32 cycles), V would run at its solo rate whatever the priorities.
+// GAP: what the M wave puts between two MFMAs.  0 nothing (the next MFMA waits at the head of the wave); 1..16: s_nop GAP-1
+// (GAP idle cycles with a SALU-class instruction at the head); 17: two s_nop (28 cycles); 20: s_sleep 0; 30: a ds_read_b128
+// of LDS garbage (an LDS-class instruction at the head, as between the MFMAs of a real K loop)
+template <int GAP> __device__ __forceinline__ void mfma_gap(const char* lds, int lane) {
+    if constexpr (GAP >= 1 && GAP <= 16) asm volatile("s_nop %0" :: "n"(GAP - 1));
+    else if constexpr (GAP == 17) asm volatile("s_nop 13\n\ts_nop 13");
+    else if constexpr (GAP == 20) asm volatile("s_sleep 0");
+    else if constexpr (GAP == 30) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 r;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((uint32_t)(lane * 16)));
+    }
+}
+template <int WITH_M, int PRIO_M, int PRIO_V, int GAP = 0>
+__global__ __launch_bounds__(512) void kv(const bf16x8* __restrict__ ops, float* out, unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float c0 = out[1], c1 = out[2];
+    float s = 0.f;
+    if (wave < 4) {
+        if (!WITH_M) return;
+        __builtin_amdgcn_s_setprio(PRIO_M);
+        bf16x8 a[4], b[2];
+        for (int i = 0; i < 4; ++i) a[i] = ops[(i * 64 + lane) & 1023];
+        for (int j = 0; j < 2; ++j) b[j] = ops[((4 + j) * 64 + lane) & 1023];
+        f32x16 acc[8];
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < 4 * iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+                mfma_gap<GAP>(nullptr, lane);
+            }
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 16; ++r) s += acc[i][r];
+        asm volatile("s_nop 0" :: "v"(s));
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) cyc[(blockIdx.x * 8 + wave) * 2] = t1 - t0;
+    } else {
+        __builtin_amdgcn_s_setprio(PRIO_V);
+        float v[40];
+        for (int i = 0; i < 40; ++i) v[i] = (float)(lane + i) * 1e-3f;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 40; ++i) v[i] = __builtin_fmaf(v[i], c0, c1);
+        for (int i = 0; i < 40; ++i) s += v[i];
+        asm volatile("s_nop 0" :: "v"(s));
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) cyc[(blockIdx.x * 8 + wave) * 2] = t1 - t0;
+    }
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int WITH_M, int PRIO_M, int PRIO_V, int GAP = 0> static void run_v(const char* name, int nwg, const bf16x8* dops, float* dout, unsigned long long* dcyc) {
+    const int iters = 10000;
+    CK(hipMemset(dcyc, 0, 4096 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL((kv<WITH_M, PRIO_M, PRIO_V, GAP>), dim3(nwg), dim3(512), 64, 0, dops, dout, dcyc, iters);
+    CK(hipDeviceSynchronize());
+    static unsigned long long h[4096];
+    CK(hipMemcpy(h, dcyc, sizeof(unsigned long long) * nwg * 16, hipMemcpyDeviceToHost));
+    double m = 0, v = 0;
+    for (int g = 0; g < nwg; ++g)
+        for (int w = 0; w < 8; ++w) (w < 4 ? m : v) += (double)h[(g * 8 + w) * 2];
+    printf("%-58s %4d workgroups: V wave %6.1f ticks per 40 v_fma (%.2f each)", name, nwg, v / (nwg * 4) / iters, v / (nwg * 4) / iters / 40);
+    if (WITH_M) printf(",  M wave %6.1f ticks per 8 MFMA", m / (nwg * 4) / (4.0 * iters));
+    printf("\n");
+}
+
 template <int B> static void run_cycles(const char* name, int nwg, const bf16x8* dops, float* dout, unsigned long long* dcyc) {
     const int iters = 20000;
     hipEvent_t e0, e1;
@@ -187,7 +261,7 @@ int main() {
     run<3, 0>("X: one wave, 1 MFMA : 5 FMA interleaved", dops, dout);
     run<3, 3>("X + X on one SIMD", dops, dout);
     unsigned long long* dcyc;
-    CK(hipMalloc(&dcyc, 2048 * sizeof(unsigned long long)));
+    CK(hipMalloc(&dcyc, 4096 * sizeof(unsigned long long)));
     printf("\n-- cycles (s_memtime) of the MFMA wave while a partner wave on the same SIMD issues VALU work for its whole lifetime --\n");
     for (int nwg : {8, 256}) {
         run_cycles<0>("M alone", nwg, dops, dout, dcyc);
@@ -195,5 +269,21 @@ int main() {
         run_cycles<5>("M + V(v_pk_fma_f32)", nwg, dops, dout, dcyc);
         run_cycles<4>("M + V(v_exp_f32)", nwg, dops, dout, dcyc);
     }
+    printf("\n-- cycles of the VALU wave while its partner (older wave slot) issues MFMAs back to back --\n");
+    for (int nwg : {8, 256}) {
+        run_v<0, 0, 0>("V alone", nwg, dops, dout, dcyc);
+        run_v<1, 0, 0>("V next to M, equal priority", nwg, dops, dout, dcyc);
+        run_v<1, 0, 3>("V next to M, s_setprio 3 on the V wave", nwg, dops, dout, dcyc);
+        run_v<1, 3, 0>("V next to M, s_setprio 3 on the M wave", nwg, dops, dout, dcyc);
+    }
+    printf("\n-- the same with something that is not a VALU-class instruction between the M wave's MFMAs (256 workgroups) --\n");
+    run_v<1, 0, 0, 4>("M: mfma; s_nop 3 (4 cycles)", 256, dops, dout, dcyc);
+    run_v<1, 0, 0, 8>("M: mfma; s_nop 7 (8 cycles)", 256, dops, dout, dcyc);
+    run_v<1, 0, 0, 16>("M: mfma; s_nop 15 (16 cycles)", 256, dops, dout, dcyc);
+    run_v<1, 0, 0, 17>("M: mfma; s_nop 13; s_nop 13 (28 cycles)", 256, dops, dout, dcyc);
+    run_v<1, 0, 0, 20>("M: mfma; s_sleep 0", 256, dops, dout, dcyc);
+    run_v<1, 0, 0, 30>("M: mfma; ds_read_b128 + lgkmcnt(0)", 256, dops, dout, dcyc);
+    run_v<1, 0, 3, 16>("M: mfma; s_nop 15, s_setprio 3 on the V wave", 256, dops, dout, dcyc);
+    run_v<1, 3, 0, 16>("M: mfma; s_nop 15, s_setprio 3 on the M wave", 256, dops, dout, dcyc);
     return 0;
 }

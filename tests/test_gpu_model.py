@@ -393,6 +393,42 @@ def test_per_bucket_optimizer_equals_one_launch_bitwise(overlap, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_optim_adamw_matches_torch():
+    """passt_amd.optim.AdamW (one fused pa_adamw launch over the flat gradient buffer the autograd node returns) against
+    torch.optim.AdamW on an identical twin, three steps of the real drop-in path with an LR scheduler; head_dist.* (never a
+    gradient) untouched by both; the staged bf16 weight copies follow the raw-pointer updates (second step's forward)."""
+    from passt_amd import optim as pa_optim
+    case = dict(G.CASES["model_small_train"], seed=931)
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    outs = []
+    for cls in (torch.optim.AdamW, pa_optim.AdamW):
+        net = build(case, "fp32").train()        # exact-f32 kernels: a bf16 weight copy would amplify 1-ulp update differences
+        opt = cls(net.parameters(), lr=1e-3, weight_decay=1e-2)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0 / (1 + e))
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(3):
+                torch.manual_seed(60 + step)
+                lo, _ = net(xg)
+                loss = torch.nn.functional.binary_cross_entropy_with_logits(lo, yg)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                sch.step()
+                losses.append(float(loss.detach()))
+        outs.append((losses, {k: v.detach().float().cpu().clone() for k, v in net.named_parameters()}, opt))
+    (l0, p0, _), (l1, p1, o1) = outs
+    assert l0[0] == l1[0] and all(abs(a - b) < 2e-6 for a, b in zip(l0, l1)), (l0, l1)
+    for k in p0:
+        assert torch.allclose(p0[k], p1[k], rtol=1e-5, atol=2e-7), k
+    # one launch covers the whole network: every live parameter is a view of the optimizer's flat buffer
+    fl = o1._flat[0]
+    assert fl["flat_p"].numel() == sum(v.numel() for v in p1.values())
+    assert sorted(o1.state_dict()["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
+
+
 def test_swa_matches_reference_update_rule():
     """schedule.SWA (one fused kernel on the flat buffer) == helpers/swa_callback.py:246-268 applied per tensor
     (restated here: avg = p for the first snapshot, then avg + (p - avg) / (n + 1)); copy_to() loads a deepcopy."""

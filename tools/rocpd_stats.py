@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--sequence", type=int, default=0, help="also list the last N dispatches in launch order")
+    ap.add_argument("--gaps", type=int, default=0, help="GPU idle time: span / busy / idle of the trace and the N largest gaps between "
+                                                        "consecutive dispatches with the kernels either side")
     args = ap.parse_args()
     con = sqlite3.connect(args.db)
     rows = con.execute("select s.kernel_name, d.start, d.end, d.dispatch_id, d.grid_size_x, d.workgroup_size_x "
@@ -52,6 +54,19 @@ def main():
         t0 = rows[-args.sequence][1] if len(rows) >= args.sequence else rows[0][1]
         for name, st, en, did, gx, wx in rows[-args.sequence:]:
             print(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.2f} {gx:9d} {short(name)}")
+    if args.gaps and rows:
+        busy_end, idle, gaps = rows[0][2], 0, []
+        for (pn, pst, pen, *_), (name, st, en, *_) in zip(rows, rows[1:]):
+            if st > busy_end:
+                idle += st - busy_end
+                gaps.append((st - busy_end, pn, name, st - rows[0][1]))
+            busy_end = max(busy_end, en)
+        span = busy_end - rows[0][1]
+        print(f"\n# GPU timeline: span {span / 1e6:.3f} ms, idle between dispatches {idle / 1e6:.3f} ms ({100.0 * idle / span:.1f} %)" +
+              (f" = {idle / 1e6 / div:.3f} ms/step" if args.steps else "") + f"; gaps > 20 us: {sum(1 for g in gaps if g[0] > 20000)}")
+        print(f"# {args.gaps} largest gaps: us idle, at ms, after kernel -> before kernel")
+        for g, pn, name, at in sorted(gaps, reverse=True)[:args.gaps]:
+            print(f"{g / 1e3:10.1f} {at / 1e6:9.2f}  {short(pn)[:48]:48s} -> {short(name)[:48]}")
     # counters
     try:
         pm = con.execute("select s.kernel_name, p.name, count(*), sum(e.value) from rocpd_pmc_event e "
