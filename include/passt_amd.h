@@ -188,6 +188,11 @@ typedef struct {
  * that run another kernel next to the GEMMs -- the gradient all-reduce of data-parallel training (ex_audioset.py:488-489): a
  * persistent launch whose workgroups cannot all be resident at once takes twice as long.  Same results. */
 #define PA_GEMM_NO_PERSIST 0x400
+/* pa_gemm_nt, bf16 role-split kernels: run this call with the LDS-free epilogue (round 4: accumulators computed transposed,
+ * rows loaded / stored straight from the registers) instead of the default one that transposes the output tile through LDS.
+ * Bit-identical results; measured slower in the training step (partial-line stores), kept for A/B measurements and the
+ * equality test.  PA_EPILOGUE_V3=1 in the environment selects it process-wide. */
+#define PA_GEMM_EPILOGUE_V3 0x1000
 int pa_gemm_blocked_pre_ok(int M, int N, int K);
 int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);

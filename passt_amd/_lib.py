@@ -101,6 +101,7 @@ SIGNATURES = {
 }
 GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flags (include/passt_amd.h)
 GEMM_NO_PERSIST = 0x400
+GEMM_EPILOGUE_V3 = 0x1000     # run a pa_gemm_nt call with the LDS-free epilogue (A/B, equality test; slower: opt-in)
 COMM_ID_BYTES = 128
 
 _lib = None

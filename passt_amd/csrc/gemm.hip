@@ -612,6 +612,221 @@ __device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f3
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue v3 (r04, opt-in): no LDS at all.  The role-split kernels can issue their MFMAs with the operands swapped
+// (template TR: acc = B-fragment x A-fragment), which leaves the TRANSPOSED tile in the accumulators: the LANE is now the
+// token row (m = lane & 31) and the registers run over the output columns, n = 8g + 4h + e for register 4g + e of the lane
+// half h = lane >> 5 -- four CONSECUTIVE columns per register group.  Same products, same k order inside the MFMA: the
+// values are bit-identical to the v2 orientation (tests/test_gpu_kernels.py::test_gemm_epilogue_v3_equals_v2).  What it buys:
+//  * f32 outputs (RESID): a register group IS a 16-byte row vector: residual rows are loaded and results stored straight
+//    from / to the registers (v2: 32 ds_write_b32 + 8 ds_read_b128 per 32x64 pass);
+//  * bf16 outputs (STORE / GELU / DGELU): the two lanes of a row hold alternating 4-column groups; one v_permlane32_swap
+//    per packed dword pair gives each lane 8 consecutive columns = one 16-byte store (the form attention.hip uses for its
+//    output rows); the pre-activation rows of DGELU come in the same way, mirrored (16-byte load, swap, unpack).  v2 spent
+//    16 ds_write_b32 + 4 ds_read_b128 + 16 v_perm per pass and output tensor there, and the LDS write issue (64 B/clk per
+//    CU) was what its transposition cost (profiles/r02_epilogue_probe.json: 24 of the 68 us of the fc1 + GELU epilogue);
+//  * the pre-activation needs no private blocked layout any more (row-major both ways, no LDS either side).
+// Not in this orientation: the column sums of the DGELU output (lane-local when the lane is the column).  The fc1.bias
+// gradient can come out of the weight-gradient launch instead (a ninth MFMA per phase against ones, as qkv.bias does:
+// PASST_AMD_BIAS_FROM_WGRAD=1); a DGELU call with colsum_out keeps the v2 kernel.
+// MEASURED SLOWER THAN v2 and therefore opt-in (see epilogue_v3_enabled): every store instruction covers 32 rows x 32 bytes
+// (two lanes per row) -- four partial-line requests per row where v2 sends one full line.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int TM> struct V3Aux {
+    static constexpr bool X = EPI == PA_EPI_DGELU, R = EPI == PA_EPI_RESID;
+    static constexpr int PASSES = X ? (PA_V2_DEPTH_X < TM ? PA_V2_DEPTH_X : TM) : 0;              // DGELU: 32-row passes in flight
+    static constexpr int HALVES = R ? (PA_V2_DEPTH_R < TM ? 2 * PA_V2_DEPTH_R : 2 * TM) : 0;  // RESID: 32-row x 32-column blocks in flight
+    static constexpr int N = X ? PASSES * 4 : HALVES * 4;        // loads per wave in issue(): the K loop's counted vmcnt wait relies on it
+    u32x4 v[N > 0 ? N : 1];
+    decltype(tile_rsrc(nullptr, 0)) rs;
+    uint32_t vofs[4], ld;       // DGELU: lane offset of chunk (j, gp) = vofs[2j + gp]; RESID: of group g = vofs[g] (block j: + 128 bytes)
+
+    __device__ __forceinline__ void issue(const pa_gemm_args& a, int m0, int n0, int wr, int wc, int lane) {
+        if constexpr (N > 0) {
+            const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
+            const bool exists = mb < a.M && nb < a.N;
+            const int q = lane & 31, h = lane >> 5;
+            if constexpr (X) {
+                ld = (uint32_t)a.ldaux * 2u;
+                rs = tile_rsrc((const char*)a.aux + ((int64_t)mb * a.ldaux + nb) * 2, exists ? ((int64_t)(a.M - mb - 1) * a.ldaux + (a.N - nb)) * 2 : 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = (c >> 1) * 32 + (c & 1) * 16 + 8 * h;
+                    vofs[c] = nb + col < a.N ? (uint32_t)q * ld + (uint32_t)col * 2u : V2_OOB;
+                }
+#pragma unroll
+                for (int i = 0; i < PASSES; ++i) load_pass(i, i);
+            } else {
+                ld = (uint32_t)a.ldr * 4u;
+                rs = tile_rsrc((const char*)a.resid + ((int64_t)mb * a.ldr + nb) * 4, exists ? ((int64_t)(a.M - mb - 1) * a.ldr + (a.N - nb)) * 4 : 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) vofs[g] = (uint32_t)q * ld + (uint32_t)(8 * g + 4 * h) * 4u;
+#pragma unroll
+                for (int hp = 0; hp < HALVES; ++hp) load_half(hp, hp, a.N - nb);
+            }
+        }
+    }
+    // DGELU: the 64 pre-activations of this lane's row in pass i, as four 16-byte chunks (j, gp)
+    __device__ __forceinline__ void load_pass(int slot, int i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[slot * 4 + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs[c] + (uint32_t)(i * 32) * ld, 0, 0);
+    }
+    // RESID: block hp = 2 i + j: the lane's four 4-column groups of row (lane & 31) of pass i
+    __device__ __forceinline__ void load_half(int slot, int hp, int ncols) {
+        const int j = hp & 1, h = threadIdx.x >> 5 & 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t o = j * 32 + 8 * g + 4 * h < ncols ? vofs[g] + (uint32_t)((hp >> 1) * 32) * ld + (uint32_t)j * 128u : V2_OOB;
+            v[slot * 4 + g] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t swap32_lo(uint32_t a, uint32_t b, uint32_t& other) {
+    // v_permlane32_swap: the upper 32 lanes of a trade places with the lower 32 lanes of b
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    other = r[1];
+    return r[0];
+}
+
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_epilogue_v3_bf16(const pa_gemm_args& a, f32x16 (&acc)[TM][2], const float* bias_row,
+                                                      int m0, int n0, int wr, int wc, int lane, V3Aux<EPI, TM>& aux) {
+    static_assert(EPI == PA_EPI_STORE || EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU, "bf16 outputs");
+    const int h = lane >> 5, q = lane & 31;
+    const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;          // uniform: origin of this wave's tile
+    if (mb >= a.M || nb >= a.N) return;
+    const int ncols = a.N - nb;
+    // lane offsets of the 16-byte chunk (j, gp): row q, columns 32 j + 16 gp + 8 h .. + 7 (N % 8 == 0: all in or all out)
+    const uint32_t ld2 = (uint32_t)a.ldolp * 2u;
+    const auto ors = tile_rsrc((const char*)a.out_lp + ((int64_t)mb * a.ldolp + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp + ncols) * 2);
+    uint32_t vo[4], vo2[4];
+    uint32_t ld2b = 0;
+    auto ors2 = ors;
+    if constexpr (EPI == PA_EPI_GELU) {
+        ld2b = (uint32_t)a.ldolp2 * 2u;
+        ors2 = tile_rsrc((const char*)a.out_lp2 + ((int64_t)mb * a.ldolp2 + nb) * 2, ((int64_t)(a.M - mb - 1) * a.ldolp2 + ncols) * 2);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = (c >> 1) * 32 + (c & 1) * 16 + 8 * h;
+        const bool ok = col < ncols && !PA_PROBE_FLAG(a, 0);
+        vo[c] = ok ? (uint32_t)q * ld2 + (uint32_t)col * 2u : V2_OOB;
+        vo2[c] = ok ? (uint32_t)q * ld2b + (uint32_t)col * 2u : V2_OOB;
+    }
+    // bias of this lane's columns: register 4g + e of block j <-> column 32 j + 8 g + 4 h + e (LDS broadcast reads)
+    f32x4 b4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            b4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI != PA_EPI_DGELU) {
+                if (bias_row) b4[j][g] = *(const f32x4*)(bias_row + wc * 64 + j * 32 + 8 * g + 4 * h);
+            }
+        }
+    float cs = 1.f;
+    if constexpr (EPI == PA_EPI_STORE) {
+        if (nb < a.colscale_n) {
+            cs = a.colscale;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b4[j][g] *= cs;
+        }
+    }
+    constexpr int XD = V3Aux<EPI, TM>::PASSES > 0 ? V3Aux<EPI, TM>::PASSES : 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);       // keep the passes apart (register pressure)
+        // DGELU: this row's pre-activations, redistributed to the accumulator's column groups: chunk (j, gp) holds columns
+        // 16 gp + 8 h + {0..7} as dwords x0..x3; group 2 gp of this lane = {lower: x0 x1, upper: lower's x2 x3}, group 2 gp + 1
+        // = {lower: upper's x0 x1, upper: x2 x3}
+        uint32_t xg[2][4][2];
+        if constexpr (EPI == PA_EPI_DGELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 x = aux.v[(i % XD) * 4 + c];
+                const int j = c >> 1, gp = c & 1;
+                xg[j][2 * gp][0] = swap32_lo(x[0], x[2], xg[j][2 * gp + 1][0]);
+                xg[j][2 * gp][1] = swap32_lo(x[1], x[3], xg[j][2 * gp + 1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the refill below must not be hoisted above the reads of its slot
+            if (i + XD < TM) aux.load_pass(i % XD, i + XD);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t w[4][2], w2[4][2];          // group g: packed {col 0, 1}, {col 2, 3} of the group
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int r = 4 * g + 2 * e2;
+                    f32x2 v = {acc[i][j][r] + b4[j][g][2 * e2], acc[i][j][r + 1] + b4[j][g][2 * e2 + 1]};
+                    if constexpr (EPI == PA_EPI_STORE) v = f32x2{fmaf(acc[i][j][r], cs, b4[j][g][2 * e2]), fmaf(acc[i][j][r + 1], cs, b4[j][g][2 * e2 + 1])};
+                    if constexpr (EPI == PA_EPI_DGELU) {
+                        const uint32_t xw = xg[j][g][e2];
+                        const f32x2 x = {__builtin_bit_cast(float, xw << 16), __builtin_bit_cast(float, xw & 0xffff0000u)};
+                        v = v * (PA_PROBE_FLAG(a, 2) ? x : gelu_grad_fast2(x));
+                    }
+                    w[g][e2] = cvt_pk_bf16(v[0], v[1]);
+                    if constexpr (EPI == PA_EPI_GELU) {
+                        const f32x2 gl = PA_PROBE_FLAG(a, 2) ? v : gelu_fast2(v);     // of the f32 value (the reference applies GELU before rounding too)
+                        w2[g][e2] = cvt_pk_bf16(gl[0], gl[1]);
+                    }
+                }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                // lower half keeps its group 2 gp and receives the upper half's; upper half keeps 2 gp + 1 and receives the lower's
+                uint32_t o0, o1;
+                const uint32_t k0 = swap32_lo(w[2 * gp][0], w[2 * gp + 1][0], o0), k1 = swap32_lo(w[2 * gp][1], w[2 * gp + 1][1], o1);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{k0, k1, o0, o1}, ors, vo[2 * j + gp] + (uint32_t)(i * 32) * ld2, 0, 0);
+                if constexpr (EPI == PA_EPI_GELU) {
+                    const uint32_t g0 = swap32_lo(w2[2 * gp][0], w2[2 * gp + 1][0], o0), g1 = swap32_lo(w2[2 * gp][1], w2[2 * gp + 1][1], o1);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{g0, g1, o0, o1}, ors2, vo2[2 * j + gp] + (uint32_t)(i * 32) * ld2b, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// out[m][n] = acc + bias[n] + resid[m][n], f32, straight from / to the registers
+template <int TM>
+__device__ __forceinline__ void gemm_epilogue_v3_resid(const pa_gemm_args& a, f32x16 (&acc)[TM][2], const float* bias_row,
+                                                       int m0, int n0, int wr, int wc, int lane, V3Aux<PA_EPI_RESID, TM>& aux) {
+    const int h = lane >> 5, q = lane & 31;
+    const int mb = m0 + wr * (TM * 32), nb = n0 + wc * 64;
+    if (mb >= a.M || nb >= a.N) return;
+    const int ncols = a.N - nb;
+    const uint32_t ldo4 = (uint32_t)a.ldo32 * 4u;
+    const auto ors = tile_rsrc((const char*)a.out_f32 + ((int64_t)mb * a.ldo32 + nb) * 4, ((int64_t)(a.M - mb - 1) * a.ldo32 + ncols) * 4);
+    uint32_t vo[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) vo[g] = (uint32_t)q * ldo4 + (uint32_t)(8 * g + 4 * h) * 4u;
+    constexpr int NH = 2 * TM, DEPTH = V3Aux<PA_EPI_RESID, TM>::HALVES;
+#pragma unroll
+    for (int hp = 0; hp < NH; ++hp) {
+        const int i = hp >> 1, j = hp & 1;
+        __builtin_amdgcn_sched_barrier(0);       // keep the blocks apart (register pressure: 256-row tiles spilled otherwise)
+        f32x4 o[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // the bias of this lane's four columns: an LDS broadcast read per group, not 32 registers held across the epilogue
+            const f32x4 b = bias_row ? *(const f32x4*)(bias_row + wc * 64 + j * 32 + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 r = __builtin_bit_cast(f32x4, aux.v[(hp % DEPTH) * 4 + g]);
+            o[g] = f32x4{acc[i][j][4 * g] + b[0], acc[i][j][4 * g + 1] + b[1], acc[i][j][4 * g + 2] + b[2], acc[i][j][4 * g + 3] + b[3]} + r;
+        }
+        __builtin_amdgcn_sched_barrier(0);       // the refill must not be hoisted above the adds (it would get fresh registers)
+        if (hp + DEPTH < NH) aux.load_half(hp % DEPTH, hp + DEPTH, ncols);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t off = (j * 32 + 8 * g + 4 * h < ncols && !PA_PROBE_FLAG(a, 0)) ? vo[g] + (uint32_t)(i * 32) * ldo4 + (uint32_t)j * 128u : V2_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[g]), ors, off, 0, 0);
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most `k * PER` of this wave's global->LDS copies are still in flight (k = 0..3)
 template <int PER> __device__ __forceinline__ void wait_vm_groups(int k) {
@@ -833,10 +1048,12 @@ template <int TM, bool A3> struct StaggerGeom {
     static constexpr int LDS = TAB_OFF + MAX_ROUNDS * 16;
 };
 
-template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false>
+// TR (r04): MFMA operands swapped -> transposed accumulators (lane = token row) and the LDS-free epilogue v3 (see there)
+template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false, bool TR = false>
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                               const int nwg, const int ksteps_per_split, const int total) {
     using G = StaggerGeom<TM, A3>;
+    static_assert(!TR || (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && !BLK), "v3: bf16 operands, fused epilogues, row-major pre-activation");
     constexpr int WN = 4;
     constexpr int TBM = G::TBM, TBN = G::TBN;         // TM = 2/3/4 -> 128/192/256-row tiles (tile quantisation)
     constexpr int A_PER = TM;                         // A copies per wave per stage: TBM*128/1024/8
@@ -956,8 +1173,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
         // saves TM x 32 v_mov per wave and item in the seam between two items
         f32x16 acc[TM][2];
         constexpr int AUX_EPI = USE_V2 ? EPI : PA_EPI_STORE;
-        V2Aux<AUX_EPI, TM, BLK> aux;
-        constexpr int AUXN = V2Aux<AUX_EPI, TM, BLK>::N;
+        std::conditional_t<TR, V3Aux<AUX_EPI, TM>, V2Aux<AUX_EPI, TM, BLK>> aux;
+        constexpr int AUXN = decltype(aux)::N;
+        static_assert(V3Aux<AUX_EPI, TM>::N == V2Aux<AUX_EPI, TM, false>::N, "both epilogues leave the same number of loads in flight");
         const int cur_m0 = m0, cur_n0 = n0, cur_split = split;
         if (wr == 1) __builtin_amdgcn_s_barrier();         // group 1 runs one barrier behind
         PA_PROBE_STAMP(round < 24, round * 16);
@@ -1022,24 +1240,25 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
                 // (r02, measured and rejected: hitting the closing barrier 1..3 MFMAs EARLY, so that the barrier's ~100-cycle
                 // resolution overlaps the tail of the M segment, is 3..7 % SLOWER -- the tail MFMAs then share the SIMD's matrix
                 // pipe with the other group's first ones: profiles/r02_kloop_experiments.json)
+                // TR: the weight fragment is the MFMA's A operand: the accumulator holds the transposed block (lane = token)
                 if (ph == 0 && t == 0) {              // uniform: first substep of the item starts the accumulation chains
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) mma32_first<T>(acc[i][j], fa[0][i], fb[0][j]);
+                        for (int j = 0; j < 2; ++j) mma32_first<T>(acc[i][j], TR ? fb[0][j] : fa[0][i], TR ? fa[0][i] : fb[0][j]);
 #pragma unroll
                     for (int u = 1; u < SUB; ++u)
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
+                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], TR ? fb[u][j] : fa[u][i], TR ? fa[u][i] : fb[u][j]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < SUB; ++u)
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], fa[u][i], fb[u][j]);
+                            for (int j = 0; j < 2; ++j) mma32<T>(acc[i][j], TR ? fb[u][j] : fa[u][i], TR ? fa[u][i] : fb[u][j]);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (ph == NPH - 1 && wr == 0) wait_tile();
@@ -1074,7 +1293,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
             // straight-line epilogue; matrix edges are handled by the buffer descriptors (launch_gemm_stagger keeps the
             // row-remapped patch-embedding form and matrices >= 2 GiB away from this kernel)
             const float* brow = HAS_BIAS && a.bias ? (const float*)(smem + G::BIAS_OFF) : nullptr;
-            if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, aux);
+            if constexpr (TR) {
+                (void)slab;
+                if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v3_resid<TM>(a, acc, brow, cur_m0, cur_n0, wr, wc, lane, aux);
+                else gemm_epilogue_v3_bf16<EPI, TM>(a, acc, brow, cur_m0, cur_n0, wr, wc, lane, aux);
+            } else if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, aux);
             else gemm_epilogue_v2_bf16<EPI, TM, BLK>(a, acc, (char*)slab, brow, cur_m0, cur_n0, wr, wc, lane, (cur_m0 / TBM) * 2 + wr, aux);
         } else if constexpr (EPI == PA_EPI_RESID || EPI == PA_EPI_PARTIAL) {
             (void)slab;
@@ -1113,9 +1336,27 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     }
 }
 
-template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false>
+// The LDS-free epilogues are OPT-IN (PA_EPILOGUE_V3=1 in the environment, or PA_GEMM_EPILOGUE_V3 on a call): bit-identical to
+// v2 and 25-40 % fewer epilogue instructions, but measured SLOWER in the step on MI355X (profiles/r04_epilogue_v3_ab.txt:
+// store 94.4 -> 99.0 us, gelu 172.6 -> 185.8, resid 106.0 -> 123.6, step 22.84 -> 23.76 ms): with two lanes per row a store
+// instruction covers 32 rows x 32 bytes, i.e. 32 partial-line write requests where v2's transposed rows give 8 full 128-byte
+// lines -- the L1 -> L2 request rate, not the instruction stream, is what the v2 transposition buys.
+static bool epilogue_v3_enabled() {
+    static const bool on = [] { const char* e = getenv("PA_EPILOGUE_V3"); return e && atoi(e) != 0; }();
+    return on;
+}
+
+template <typename T, int EPI, int TM, bool A3 = false, bool BLK = false, bool TR = false>
 static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     using G = StaggerGeom<TM, A3>;
+    // the LDS-free epilogue (transposed accumulators) wherever it applies: bf16 operands, a fused epilogue, row-major
+    // pre-activation, no column sums asked of the DGELU epilogue (they are lane-local only in the v2 orientation)
+    // (the 256-row RESID tile keeps v2: 128 accumulators + 32 residual registers in flight spill in the v3 form)
+    if constexpr (!TR && !BLK && PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && !(EPI == PA_EPI_RESID && TM == 4)) {
+        if ((epilogue_v3_enabled() || (a.reserved & PA_GEMM_EPILOGUE_V3)) && !(EPI == PA_EPI_DGELU && a.colsum_out) &&
+            !(EPI == PA_EPI_RESID && a.row_mod > 0))
+            return launch_gemm_stagger<T, EPI, TM, A3, false, true>(a, st);
+    }
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     const int tiles_m = (int)cdiv(a.M, 64 * TM), tiles_n = (int)cdiv(a.N, 256);
     const int nwg = tiles_m * tiles_n;
@@ -1133,7 +1374,7 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
         (PA_EPILOGUE_V2 && sizeof(T) == 2 && EPI != PA_EPI_PARTIAL && (big || (EPI == PA_EPI_RESID && a.row_mod > 0))))
         return BLK ? PA_EUNSUPPORTED : launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);     // (the generic kernel has no blocked form)
     if constexpr (A3) {      // two K-tiles of lead need two K-tiles in every item; the short item table bounds the rounds
-        if (ksteps - (splits - 1) * per < 2 || per < 2 || cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_stagger<T, EPI, TM, false, BLK>(a, st);
+        if (ksteps - (splits - 1) * per < 2 || per < 2 || cdiv(total, 256) > G::MAX_ROUNDS) return launch_gemm_stagger<T, EPI, TM, false, BLK, TR>(a, st);
     } else {
         if (cdiv(total, 256) > G::MAX_ROUNDS) return BLK ? PA_EUNSUPPORTED : launch_gemm_v<T, EPI, 2, 2, 2, 2>(a, st);
     }
@@ -1144,7 +1385,7 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
 #endif
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (probe build)");
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>,
+        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK, TR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     }();
     (void)attr_set;
@@ -1154,7 +1395,7 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     // others have finished ALL their items and the launch takes twice as long; one item per workgroup degrades by R / 256.
     static const bool persist_env = [] { const char* e = getenv("PA_NT_PERSISTENT"); return !e || atoi(e) != 0; }();
     const bool persistent = persist_env && !(a.reserved & PA_GEMM_NO_PERSIST);
-    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK>), dim3(persistent ? std::min(total, 256) : total), dim3(512), LDS_BYTES, st, a,
+    hipLaunchKernelGGL((gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK, TR>), dim3(persistent ? std::min(total, 256) : total), dim3(512), LDS_BYTES, st, a,
                        tiles_m, tiles_n, nwg, per, total);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * 2, st);
@@ -2213,7 +2454,10 @@ extern "C" int pa_gemm_nt_splitk_plan(int M, int N, int K, int epilogue, int dty
     const int ksteps = K * 2 / KB;
     if (tiles > 128 || ksteps < 16) return 1;
     // at least 6 K-tiles per slice (prologue and slab write stay a small part of an item), at most 16 slices
-    const int s = (int)std::min<int64_t>(std::min<int64_t>(256 / tiles, ksteps / 6), 16);
+    int s = (int)std::min<int64_t>(std::min<int64_t>(256 / tiles, ksteps / 6), 16);
+    // every slice must hold at least one K-tile: with ceil-divided slices the last ones can come out empty (97 K-tiles in 16
+    // slices of 7: slices 14 and 15 are empty), and the role-split kernel then hands the whole problem to the generic one
+    while (s >= 2 && (int64_t)(s - 1) * cdiv(ksteps, s) >= ksteps) --s;
     return s >= 2 ? s : 1;
 }
 
@@ -2239,6 +2483,8 @@ extern "C" int pa_gemm_nt_splitk(const pa_gemm_args* a, float* ws, int64_t ws_fl
     const int v = pick_nt_variant(a->M, a->N, a->K);
     p.tune = v == 6 ? 6 : v + 10;            // the 192- / 128-row tiles with A two K-tiles ahead where a slice allows it
     int rc = pa_gemm_nt(&p, stream);
+    // drop-in for pa_gemm_nt: a shape the partial form does not cover runs unsplit instead of failing
+    if (rc == PA_EUNSUPPORTED || rc == PA_EINVAL) return pa_gemm_nt(a, stream);
     if (rc != PA_OK) return rc;
     const int64_t vecs = (int64_t)a->M * (a->N / 4);
     const int blocks = (int)std::min<int64_t>(cdiv(vecs, 256), 2048);
@@ -2332,6 +2578,9 @@ extern "C" int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, 
 extern "C" int64_t pa_gemm_blocked_pre_elems(int M, int N) { return blocked_pre_rows(M) * N; }
 // 1 when pa_gemm_nt with tune = 0 runs the bf16 M x N x K GELU / DGELU GEMMs on a kernel that has the blocked form
 extern "C" int pa_gemm_blocked_pre_ok(int M, int N, int K) {
+    // the LDS-free epilogues (v3, opt-in) write and read the pre-activation row-major without any transposition: the
+    // private blocked layout only exists for the v2 kernels
+    if (epilogue_v3_enabled()) return 0;
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64 || blocked_pre_rows(M) * N * 2 >= ((int64_t)1 << 31)) return 0;
     const int v = pick_nt_variant(M, N, K);
     if (v != 6 && v != 7 && v != 8) return 0;

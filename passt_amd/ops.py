@@ -86,16 +86,24 @@ class _PinnedRing:
     stream in a data-parallel run.  Four slots per (device, dtype, length) rotate; a slot is reused only after the event
     behind its last copy has fired."""
 
+    MAX_RINGS = 32          # distinct (device, dtype, length) rings kept: variable-length uploads must not pin memory without bound
+
     def __init__(self, slots=4):
         self.slots, self.rings = slots, {}
 
     def upload(self, host, device):
         host = torch.as_tensor(host)
         key = (str(device), host.dtype, host.numel())
-        ring = self.rings.get(key)
+        ring = self.rings.pop(key, None)            # re-inserted below: the dict is kept in least-recently-used order
         if ring is None:
-            ring = self.rings[key] = {"i": 0, "buf": [torch.empty(host.numel(), dtype=host.dtype).pin_memory() for _ in range(self.slots)],
-                                      "ev": [None] * self.slots}
+            while len(self.rings) >= self.MAX_RINGS:
+                old = self.rings.pop(next(iter(self.rings)))
+                for ev in old["ev"]:                # its copies must have left the page-locked buffers before they are freed
+                    if ev is not None:
+                        ev.synchronize()
+            ring = {"i": 0, "buf": [torch.empty(host.numel(), dtype=host.dtype).pin_memory() for _ in range(self.slots)],
+                    "ev": [None] * self.slots}
+        self.rings[key] = ring
         i = ring["i"]
         ring["i"] = (i + 1) % self.slots
         if ring["ev"][i] is not None:
@@ -125,7 +133,9 @@ GEMM_PROFILE = None
 PROFILE_BY_SHAPE = bool(os.environ.get("PASST_AMD_PROFILE_BY_SHAPE"))     # bench.py per_epilogue keyed by (epilogue, M, N, K)
 GEMM_TUNE = 0          # pa_gemm_args.tune for every pa_gemm_nt call (0 = library default)
 TN_BATCH_ORDER = int(os.environ.get("PASST_AMD_TN_ORDER", "0"))   # 2: problem-major item order (A/B only, see gemm.hip)
-GEMM_RESERVED = 0      # pa_gemm_args.reserved (ignored by the product library; probe builds: tools/probe_epilogue.py)
+# pa_gemm_args.reserved of every pa_gemm_nt call (probe builds: tools/probe_epilogue.py; A/B: PASST_AMD_GEMM_FLAGS=0x1000 =
+# _lib.GEMM_EPILOGUE_V3, the LDS-free epilogues)
+GEMM_RESERVED = int(os.environ.get("PASST_AMD_GEMM_FLAGS", "0"), 0)
 _EPI_NAME = {EPI_STORE: "store", EPI_GELU: "gelu", EPI_RESID: "resid", EPI_DGELU: "dgelu", EPI_PARTIAL: "wgrad_partial"}
 
 

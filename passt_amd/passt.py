@@ -372,14 +372,18 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     # bf16, single stream: the four weight gradients of a block wait until the block's last operand exists and go out as
     # ONE batched launch (+ one batched split-K reduction): no drain / prologue between them, equal-sized work items
     pending = [] if (dt == PA_BF16 and not side.enabled and not os.environ.get("PASST_AMD_NO_BATCH_WGRAD")) else None
+    # PASST_AMD_BIAS_FROM_WGRAD=1 (A/B; required by PA_EPILOGUE_V3=1): fc1.bias out of the weight-gradient launch instead of the
+    # GELU' epilogue's lane-local column sums
+    bias_from_wgrad = (dt == PA_BF16 and ops.wgrad_tn_fuses_bias(dt) and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
+                       and (os.environ.get("PASST_AMD_BIAS_FROM_WGRAD") == "1" or os.environ.get("PA_EPILOGUE_V3") == "1"))
 
-    def wgrad(dY, X, dW, db, done=None):
+    def wgrad(dY, X, dW, db, done=None, fuse=False):
         if pending is None:
             return wgrad_async(dY, X, dW, db, done)
-        # the block's last problem (qkv) gets its bias gradient out of the batched launch itself (a ninth MFMA per phase
-        # in the tiles of the first X-column block); earlier ones with a bias (compact fc2 of the last block) use the
+        # the block's last problem (qkv) -- and fc1, `fuse` -- get their bias gradient out of the batched launch itself (a
+        # ninth MFMA per phase in the tiles of the first X-column block); the compact fc2 of the last block uses the
         # column-sum kernel right away
-        fused_bias = done is not None and db is not None and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
+        fused_bias = (done is not None or fuse) and db is not None and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
         pending.append((dY, X, dW.view(dY.shape[1], -1), False, db if fused_bias else None))
         if db is not None and not fused_bias:
             ops.colsum(dY, db)
@@ -411,11 +415,17 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         # fc2.bias gradient = column sums of dx: already produced by the LayerNorm backward that made dx (the next
         # block's norm1) -- except for the last block, whose dx comes from the head
         wgrad(dx_lp, h_act, g[pfx + "mlp.fc2.weight"], g[pfx + "mlp.fc2.bias"] if last else None)
-        # the fc1.bias gradient (column sums of d_pre) comes out of the same epilogue
-        cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(h_pre.shape[0], h_pre.shape[1], dx_lp.device, scratch.get("colsum_ws"))
-        d_pre = ops.dgelu_gemm(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), h_pre, dt,
-                               colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
-        wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
+        if bias_from_wgrad:
+            # the fc1.bias gradient (column sums of d_pre) rides in the weight-gradient launch, like qkv.bias (the LDS-free
+            # GELU' epilogue -- transposed accumulators, lane = token -- has no lane-local column sums to offer)
+            d_pre = ops.dgelu_gemm(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), h_pre, dt)
+            wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], g[pfx + "mlp.fc1.bias"], fuse=True)
+        else:
+            # the fc1.bias gradient (column sums of d_pre) comes out of the GELU' epilogue
+            cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(h_pre.shape[0], h_pre.shape[1], dx_lp.device, scratch.get("colsum_ws"))
+            d_pre = ops.dgelu_gemm(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), h_pre, dt,
+                                   colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
+            wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
         d_ln2 = torch.empty_like(ln2)
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
         del d_pre

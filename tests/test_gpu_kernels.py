@@ -304,6 +304,38 @@ def test_gemm_one_item_per_workgroup_is_bit_identical(M, N, K):
     assert rel_err(base[1], A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu() + resid.double().cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(474 * 4, 2304, 768), (3792, 3072, 768), (333, 768, 3072), (77, 192, 128), (1000, 768, 768),
+                                   (4236, 768, 2304), (130, 3072, 768)])
+def test_gemm_epilogue_v3_equals_v2(M, N, K):
+    """The LDS-free epilogues (round 4, opt-in PA_GEMM_EPILOGUE_V3: accumulators computed transposed -- lane = token row --,
+    rows stored straight from the registers) against the default v2 epilogues (tile transposed through LDS): same products, same k order
+    inside the MFMA, same epilogue arithmetic per element => BIT-identical outputs, for every fused epilogue, on interior
+    and edge tiles (M not a multiple of 32, N below one tile).  Values are checked against fp64 once as well."""
+    A = rnd(M, K, seed=21).to(torch.bfloat16).to(DEV)
+    Bm = rnd(N, K, seed=22, scale=0.05).to(torch.bfloat16).to(DEV)
+    bias = rnd(N, seed=23).to(DEV)
+    resid = rnd(M, N, seed=24).to(DEV)
+    dy = rnd(M, K, seed=25).to(torch.bfloat16).to(DEV)
+    outs = {}
+    for tag, fl in (("v3", ops._lib.GEMM_EPILOGUE_V3), ("v2", 0)):
+        st = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(A, Bm, PA_BF16, ops.EPI_STORE, bias=bias, out_lp=st, flags=fl, colscale_n=min(N, 128) // 64 * 64, colscale=0.37)
+        pre, act = torch.empty_like(st), torch.empty_like(st)
+        ops.gemm_nt(A, Bm, PA_BF16, ops.EPI_GELU, bias=bias, out_lp=pre, out_lp2=act, flags=fl)
+        dpre = torch.empty_like(st)
+        ops.gemm_nt(dy, Bm, PA_BF16, ops.EPI_DGELU, aux=pre, out_lp=dpre, flags=fl)
+        res = torch.empty(M, N, device=DEV, dtype=torch.float32)
+        ops.gemm_nt(A, Bm, PA_BF16, ops.EPI_RESID, bias=bias, resid=resid, out_f32=res, flags=fl)
+        torch.cuda.synchronize()
+        outs[tag] = (st, pre, act, dpre, res)
+    for name, a, b in zip(("store", "pre", "act", "dgelu", "resid"), outs["v3"], outs["v2"]):
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    ref = A.double().cpu() @ Bm.double().cpu().T + bias.double().cpu()
+    assert rel_err(outs["v3"][1], ref) < 1e-2
+    assert rel_err(outs["v3"][2], torch.nn.functional.gelu(ref)) < 1e-2
+    assert rel_err(outs["v3"][4], ref + resid.double().cpu()) < 1e-4
+
+
 def _attn_ref(qkv, B, H, N, scale, d_o=None):
     D = H * 64
     t = qkv.double().cpu().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
