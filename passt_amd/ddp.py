@@ -68,7 +68,7 @@ class RcclAbiTransport:
             comm = C.c_void_p()
             _lib.check(lib.pa_comm_init(box[0], self.rank, self.world, C.byref(comm)), "pa_comm_init")
         self.comm = comm
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)     # high priority: buckets start at the next kernel boundary
 
     def all_reduce(self, t):
         """In-place sum of the contiguous f32 / bf16 tensor ``t`` over the ranks; returns a handle with wait()."""
