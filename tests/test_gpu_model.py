@@ -423,7 +423,15 @@ def test_optim_adamw_matches_torch():
     assert l0[0] == l1[0] and all(abs(a - b) < 1e-5 for a, b in zip(l0, l1)), (l0, l1)
     # three AdamW steps move every entry by ~1e-3 (lr * sign-like ratio): the two implementations differ in rounding only
     # (lerp vs b1*m + (1-b1)*g, division order), far below 1e-6; a wrong bias correction or decay would show at 1e-5 .. 1e-3
-    worst = max(float((p0[k] - p1[k]).abs().max()) for k in p0)
+    # (the key third of qkv.bias has a TRUE gradient of zero -- a bias on the keys shifts every score of a row equally --, its
+    # computed gradient is round-off noise ~1e-10 that flips with any 1-ulp change upstream, and AdamW turns noise of the size
+    # of eps into steps of lr * g / (|g| + eps): left out, as in the TrainStep-vs-oracle test)
+    def keep(k, t):
+        if not k.endswith("attn.qkv.bias"):
+            return t
+        third = t.numel() // 3
+        return torch.cat([t[:third], t[2 * third:]])
+    worst = max(float((keep(k, p0[k]) - keep(k, p1[k])).abs().max()) for k in p0)
     moved = max(float((p0[k] - torch.from_numpy(detgen.passt_state_dict(case["cfg"], case["seed"])[k])).abs().max()) for k in p0)
     record("optim_adamw_vs_torch", worst_param_diff=worst, largest_update=moved, loss_diff=max(abs(a - b) for a, b in zip(l0, l1)))
     assert worst < 2e-6 and moved > 1e-3, (worst, moved)
