@@ -305,32 +305,46 @@ def self_launch(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import signal
+    import tempfile
     procs = []
+    # rank 0's stdout goes to a file, not a pipe: nothing can block on a full pipe while the parent polls.  The children stay
+    # in the parent's process group (a group kill by whoever started us takes them along) and are killed if we are terminated.
+    out0_file = tempfile.TemporaryFile()
+
+    def reap(signum=None, frame=None):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if signum is not None:
+            sys.exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, reap)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PASST_AMD_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+                                      stdout=out0_file if r == 0 else sys.stderr))
     failed = None
     deadline = time.time() + float(os.environ.get("PASST_AMD_BENCH_TIMEOUT_S", "1500"))
-    while True:
-        rcs = [p.poll() for p in procs]
-        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
-        if bad:
-            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
-        elif time.time() > deadline:
-            failed = "timed out"
-        if failed or all(rc == 0 for rc in rcs):
-            break
-        time.sleep(0.2)
-    if failed:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    out0 = procs[0].stdout.read().decode(errors="replace")
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            elif time.time() > deadline:
+                failed = "timed out"
+            if failed or all(rc == 0 for rc in rcs):
+                break
+            time.sleep(0.2)
+    finally:
+        reap()
     for p in procs:
         p.wait()
+    out0_file.seek(0)
+    out0 = out0_file.read().decode(errors="replace")
     lines = [l for l in out0.splitlines() if l.startswith("{")]
     if failed or len(lines) != 1:
         error_line(args, failed or f"rank 0 printed {len(lines)} JSON lines", launcher="self (one child per rank)")
@@ -359,6 +373,9 @@ def main():
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="weight-gradient kernels on a second stream, one launch per problem (A/B only: since the batched "
                          "per-block launch it measures the same as the default, profiles/r03_finish_stream_experiment.txt)")
+    ap.add_argument("--graph", action="store_true",
+                    help="TrainStep(graph=True): forward + loss + backward + per-bucket AdamW captured once as a hipGraph and replayed "
+                         "(single GPU; no per-launch events, so the line carries no roofline object: a host-overhead measurement)")
     ap.add_argument("--path", default="trainstep", choices=["trainstep", "autograd"],
                     help="trainstep: passt_amd.train.TrainStep (fused mixup / loss / AdamW, no autograd graph).  autograd: what an "
                          "UNMODIFIED ex_audioset.py runs -- mel -> torch mixup -> net(x) (one autograd Function) -> torch BCE -> "
@@ -438,7 +455,7 @@ def run(args):
                           comm_dtype=args.comm_dtype, transport=args.transport, optimizer=args.optimizer)
     else:
         ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
-                       loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport)
+                       loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport, graph=args.graph)
     B = args.batch or cfgd["batch"]
     frames = 998 if cfgd["clip"] == CLIP_SAMPLES else 1 + (cfgd["clip"] - 1) // 320     # --no-mel: the reference's speed-test shape
     if args.no_mel:
@@ -464,7 +481,7 @@ def run(args):
             ts.phases.clear()                   # phase diagnostics: timed steps only (warm-up carries one-time module loads)
         # per-launch HIP events on the GEMM family (roofline): two event records per launch cost ~3.4 % of the step
         # when every step is instrumented, so one timed step in PROFILE_EVERY carries them (always including step 0)
-        prof = {} if (rank == 0 and not args.no_roofline) else None
+        prof = {} if (rank == 0 and not args.no_roofline and not args.graph) else None
         t0 = time.perf_counter()
         for i in range(args.steps):
             ops.GEMM_PROFILE = prof if (prof is not None and i % PROFILE_EVERY == 0) else None
@@ -539,7 +556,9 @@ def run(args):
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
-                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW)" if args.path == "trainstep" else
+                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW)"
+                                + (", network forward + loss + backward + AdamW replayed from one captured hipGraph" if args.graph else "")
+                                if args.path == "trainstep" else
                                 "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
                                 + {"adamw": "AdamW (multi-tensor default)", "sgd": "SGD", "pa_adamw": "AdamW replaced by passt_amd.optim.AdamW"}[args.optimizer]
                                 + (", passt_amd.ddp.attach(net)" if world > 1 else "")),

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define PA_ABI_VERSION 4   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
-                            * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info */
+                            * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info, pa_adamw_dev / pa_adamw_hyper, PA_GEMM_EPILOGUE_V3 */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -363,6 +363,12 @@ int pa_wave_augment(const float* x, int B, int64_t ldx, const int32_t* len, cons
 /* torch.optim.AdamW (ex_audioset.py:104-109) on one flat f32 parameter buffer */
 int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same update with the step's scalars in DEVICE memory: hyper = 7 floats [lr, beta1, beta2, eps, weight_decay,
+ * 1 - beta1^step, sqrt(1 - beta2^step)] (pa_adamw_hyper fills a HOST array of 7 with exactly what pa_adamw computes from its
+ * by-value arguments; the caller copies it to the device).  The launch's arguments are then the same every step, so it can be
+ * part of a captured hipGraph (passt_amd.train.TrainStep(graph=True)). */
+int pa_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
+void pa_adamw_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* hyper7_host);
 /* torch.optim.SGD lr only (ex_audioset.py:392 model_speed_test) */
 int pa_sgd(float* p, const float* g, int64_t n, float lr, void* stream);
 /* Stochastic weight averaging step on flat buffers (helpers/swa_callback.py:246-268, update_parameters + avg_fn):

@@ -89,6 +89,8 @@ SIGNATURES = {
     "pa_ce_mixup_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     "pa_mixup": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "pa_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "pa_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "pa_adamw_hyper": (None, [f32, f32, f32, f32, f32, i32, C.POINTER(f32)]),
     "pa_sgd": (i32, [vp, vp, i64, f32, vp]),
     "pa_swa_update": (i32, [vp, vp, i64, i32, vp]),
     "pa_wave_augment": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]),

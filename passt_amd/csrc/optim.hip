@@ -58,6 +58,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     for (int64_t i = n4 * 4 + t0; i < n; i += stride) adamw_one(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
 }
 
+// the same update with the hyper-parameters of the step read from device memory ([lr, beta1, beta2, eps, weight_decay,
+// 1 - beta1^t, sqrt(1 - beta2^t)]): a launch whose arguments never change, i.e. one that can sit in a captured hipGraph
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n4, int64_t n, const float* __restrict__ hy) {
+    const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], bc1 = hy[5], bc2_sqrt = hy[6];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4; i += stride) {
+        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pv[e], me = mv[e], ve = vv[e];
+            adamw_one(pe, gv[e], me, ve, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+            pv[e] = pe; mv[e] = me; vv[e] = ve;
+        }
+        ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+    }
+    for (int64_t i = n4 * 4 + t0; i < n; i += stride) adamw_one(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+}
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] -= lr * g[i];
@@ -145,6 +165,21 @@ extern "C" int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n,
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, sqrtf(bc2));
     return check_launch();
+}
+
+extern "C" int pa_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) return PA_EINVAL;
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const int blocks = (int)std::min<int64_t>(cdiv(std::max<int64_t>(n4, 1), 256), 8192);
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, hyper);
+    return check_launch();
+}
+
+extern "C" void pa_adamw_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* hyper7_host) {
+    hyper7_host[0] = lr; hyper7_host[1] = beta1; hyper7_host[2] = beta2; hyper7_host[3] = eps; hyper7_host[4] = weight_decay;
+    hyper7_host[5] = 1.f - powf(beta1, (float)step);
+    hyper7_host[6] = sqrtf(1.f - powf(beta2, (float)step));
 }
 
 extern "C" int pa_wave_augment(const float* x, int B, int64_t ldx, const int32_t* len, const float* amp, const int32_t* shift,

@@ -756,6 +756,18 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
           "pa_adamw")
 
 
+def adamw_dev(p, g, m, v, hyper_dev):
+    """the same update with the step's scalars in device memory (7 floats, see adamw_hyper): capturable in a hipGraph"""
+    check(_lib.load().pa_adamw_dev(_p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32), p.numel(),
+                                   _p(hyper_dev, torch.float32), _stream()), "pa_adamw_dev")
+
+
+def adamw_hyper(lr, beta1, beta2, eps, wd, step, out_host):
+    """fill the 7-float HOST tensor `out_host` with [lr, beta1, beta2, eps, wd, 1 - beta1^step, sqrt(1 - beta2^step)]"""
+    assert out_host.dtype == torch.float32 and out_host.numel() == 7 and not out_host.is_cuda
+    _lib.load().pa_adamw_hyper(lr, beta1, beta2, eps, wd, int(step), C.cast(out_host.data_ptr(), C.POINTER(C.c_float)))
+
+
 def swa_update(avg, p, num_averaged):
     """avg = p if num_averaged == 0 else avg + (p - avg) / (num_averaged + 1), flat f32 buffers."""
     check(_lib.load().pa_swa_update(_p(avg, torch.float32), _p(p, torch.float32), p.numel(), int(num_averaged), _stream()), "pa_swa_update")

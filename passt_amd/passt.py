@@ -225,13 +225,33 @@ def _precision(model):
     return PA_BF16 if torch.is_autocast_enabled() else PA_F32
 
 
-def passt_forward(model, x, save):
-    """Kernel sequence of PaSST.forward (:576-595).  Returns (logits, features, ctx)."""
+def patchout_draws(model, x_shape):
+    """The host part of a forward: geometry checks and the reference's Patchout draws (models/passt.py:513-553, same torch CPU
+    RNG calls in the same order), as numpy arrays: the grid coordinates of the kept patches (pf, pt) and the time-positional
+    offset.  passt_forward() calls this itself; TrainStep's captured-graph mode calls it ahead of the replay and hands the
+    result over in device buffers of fixed address."""
+    B, Cin, F, T = x_shape
+    P, (fs, ts) = model.patch_embed.patch_size[0], model.patch_embed.stride
+    if not (F == model.patch_embed.img_size[0] and T == model.patch_embed.img_size[1]):
+        warnings.warn(f"Input image size ({F}*{T}) doesn't match model "
+                      f"({model.patch_embed.img_size[0]}*{model.patch_embed.img_size[1]}).")   # :320-321
+    F_dim, T_dim = (F - P) // fs + 1, (T - P) // ts + 1
+    Fpe = model.freq_new_pos_embed.shape[-2]
+    if F_dim != Fpe:
+        raise RuntimeError(f"patch grid has {F_dim} frequency rows but freq_new_pos_embed has {Fpe}")
+    toff, T_eff, idx_t, idx_f, idx_u = draw_patchout(model, F_dim, T_dim)
+    pf_np, pt_np = kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u)
+    return dict(pf=pf_np, pt=pt_np, toff=toff, Np=pf_np.size)
+
+
+def passt_forward(model, x, save, draws=None):
+    """Kernel sequence of PaSST.forward (:576-595).  Returns (logits, features, ctx).  ``draws``: device-resident Patchout
+    draws {pf, pt, pt_pos (= pt + time offset), Np} prepared by the caller (captured-graph mode); None = draw here."""
     with ops.gemm_flags(getattr(model, "_gemm_flags", 0)):
-        return _passt_forward(model, x, save)
+        return _passt_forward(model, x, save, draws)
 
 
-def _passt_forward(model, x, save):
+def _passt_forward(model, x, save, draws=None):
     if not x.is_cuda:
         raise PasstAmdError("passt_amd.PaSST runs on a HIP device only (no CPU fallback); got a CPU tensor")
     dt = _precision(model)
@@ -242,19 +262,14 @@ def _passt_forward(model, x, save):
                          "(in_chans = 1 in every reference arch, models/passt.py:961)")
     B, Cin, F, T = x.shape
     P, (fs, ts) = model.patch_embed.patch_size[0], model.patch_embed.stride
-    if not (F == model.patch_embed.img_size[0] and T == model.patch_embed.img_size[1]):
-        warnings.warn(f"Input image size ({F}*{T}) doesn't match model "
-                      f"({model.patch_embed.img_size[0]}*{model.patch_embed.img_size[1]}).")   # :320-321
-    F_dim, T_dim = (F - P) // fs + 1, (T - P) // ts + 1
-    Tpe, Fpe = model.time_new_pos_embed.shape[-1], model.freq_new_pos_embed.shape[-2]
-    if F_dim != Fpe:
-        raise RuntimeError(f"patch grid has {F_dim} frequency rows but freq_new_pos_embed has {Fpe}")
-    toff, T_eff, idx_t, idx_f, idx_u = draw_patchout(model, F_dim, T_dim)
-    pf_np, pt_np = kept_patches(F_dim, T_eff, idx_t, idx_f, idx_u)
-    pf = ops.upload_small(pf_np, x.device)         # page-locked staging: asynchronous H2D
-    pt = ops.upload_small(pt_np, x.device)
+    if draws is None:
+        d = patchout_draws(model, x.shape)
+        pf = ops.upload_small(d["pf"], x.device)         # page-locked staging: asynchronous H2D
+        pt = ops.upload_small(d["pt"], x.device)
+        pt_pos, toff, Np = pt, d["toff"], d["Np"]        # the positional kernels add the offset themselves
+    else:
+        pf, pt, pt_pos, toff, Np = draws["pf"], draws["pt"], draws["pt_pos"], 0, draws["Np"]
     D, H, depth = model.embed_dim, model.num_heads, len(model.blocks)
-    Np = pf_np.size
     Ntok, M = Np + 2, B * (Np + 2)
     scale = (D // H) ** -0.5
 
@@ -263,7 +278,7 @@ def _passt_forward(model, x, save):
     cols = ops.patch_gather(x, pf, pt, P, fs, ts, dt)
     tok = torch.empty((B, Ntok, D), device=x.device, dtype=torch.float32)
     table = ops.patch_pos_table(model.patch_embed.proj.bias, model.time_new_pos_embed, model.freq_new_pos_embed,
-                                pf, pt, toff, model.cls_token, model.dist_token, model.new_pos_embed, tok)
+                                pf, pt_pos, toff, model.cls_token, model.dist_token, model.new_pos_embed, tok)
     ops.gemm_nt(cols, st.get(model.patch_embed.proj.weight, dt, False), dt, EPI_RESID, resid=table, out_f32=tok,
                 row_mod=Np, out_batch_rows=Ntok, out_row_off=2)
 
@@ -302,7 +317,7 @@ def _passt_forward(model, x, save):
     logits = ops.linear_f32_fwd(hn, model.head[1].weight, model.head[1].bias)
     ctx = None
     if save:
-        ctx = dict(dt=dt, B=B, Ntok=Ntok, Np=Np, pf=pf, pt=pt, toff=toff, cols=cols, saved=saved, xl=xl, feat=feat,
+        ctx = dict(dt=dt, B=B, Ntok=Ntok, Np=Np, pf=pf, pt=pt_pos, toff=toff, cols=cols, saved=saved, xl=xl, feat=feat,
                    hn=hn, stats=stats, scale=scale)
     return logits, feat, ctx
 

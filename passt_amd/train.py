@@ -14,12 +14,17 @@ import torch
 
 from . import ops
 from .ddp import GradReducer
-from .passt import passt_backward, passt_forward
+from .passt import passt_backward, passt_forward, patchout_draws
 
 
 class TrainStep:
     def __init__(self, net, mel=None, lr=2e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, optimizer="adamw",
-                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce", comm_dtype="fp32", transport="torch"):
+                 mixup_alpha=0.3, use_mixup=True, process_group=None, loss="bce", comm_dtype="fp32", transport="torch", graph=False):
+        """graph=True (single GPU): after ``graph_warmup`` eager steps the network's forward, the loss, the backward and the
+        per-bucket optimizer launches (~290 of the step's ~300 launches) are captured once as a hipGraph (torch.cuda.CUDAGraph)
+        and replayed; only the front end, mixup and the uploads of the step's host-drawn arrays stay eager.  Same kernels, same
+        arguments, bit-identical parameters (tests/test_gpu_model.py::test_train_step_graph_equals_eager); what changes is the
+        host: one replay instead of ~290 ctypes launches -- it matters where the step is short (ESC-50 at batch 12)."""
         self.net, self.mel = net, mel
         self.lr, self.wd, self.betas, self.eps, self.optimizer = lr, weight_decay, betas, eps, optimizer
         self.mixup_alpha, self.use_mixup = mixup_alpha, use_mixup
@@ -59,12 +64,19 @@ class TrainStep:
             # Per model (net._gemm_flags rides on every pa_gemm_nt call of this net's forward / backward); close() undoes it.
             object.__setattr__(net, "_gemm_flags", getattr(net, "_gemm_flags", 0) | ops._lib.GEMM_NO_PERSIST)
             self._set_no_persist = True
+        self.graph = bool(graph) and self.reducer.world == 1
+        self.graph_warmup, self._g = 3, None
         self.t = self._t_now = 0
         self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
         self.base_lr = lr
         net.mark_params_updated()
 
     def _optimizer(self, s, e):
+        if self._g is not None and self._g.get("capturing"):
+            # inside the capture: the step's scalars come from device memory (launch arguments must not change between replays)
+            if self.optimizer != "adamw":
+                raise NotImplementedError("graph mode: AdamW only")
+            return ops.adamw_dev(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self._g["hyper"])
         if self.optimizer == "adamw":
             ops.adamw(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self.lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, self._t_now)
@@ -95,6 +107,36 @@ class TrainStep:
         schedule.exp_warmup_linear_down(5, 50, 50, 0.01)(epoch)."""
         self.lr = self.base_lr * float(factor)
 
+    # ---- captured-graph mode ------------------------------------------------------------------------------------------
+    def _graph_fill(self, g, d, x, y, y2, lam_d):
+        g["x"].copy_(x)
+        g["y"].copy_(y)
+        if y2 is not None:
+            g["y2"].copy_(y2)
+        if lam_d is not None:
+            g["lam"].copy_(lam_d)
+        g["pf"].copy_(ops.upload_small(d["pf"], x.device))
+        g["pt"].copy_(ops.upload_small(d["pt"], x.device))
+        g["pt_pos"].copy_(ops.upload_small(d["pt"] + np.int32(d["toff"]), x.device))
+        # (through the pinned ring like the index arrays: a fixed host buffer could be rewritten for step k + 1 before the
+        # asynchronous copy of step k has read it)
+        ops.adamw_hyper(self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self._t_now, g["hyper_host"])
+        g["hyper"].copy_(ops.upload_small(g["hyper_host"], x.device))
+
+    def _graph_body(self, g):
+        net = self.net
+        logits, feat, ctx = passt_forward(net, g["x"], save=True, draws=g)
+        if self.loss == "bce":
+            loss, dlogits = ops.bce_fwd_bwd(logits, g["y"], grad_scale=1.0)
+        elif g["y2"] is not None:
+            loss, dlogits = ops.ce_mixup_fwd_bwd(logits, g["y"], g["y2"], g["lam"], grad_scale=1.0)
+        else:
+            loss, dlogits = ops.ce_mixup_fwd_bwd(logits, g["y"], grad_scale=1.0)
+        passt_backward(net, ctx, dlogits, None, self.grads, on_block_done=self._block_done)
+        if not self.block_optimizer:
+            self._optimizer(0, self.flat_p.numel())
+        return loss
+
     def step(self, wave_or_spec, target):
         """wave (B,1,L) / (B,L) when a mel module was given, else a spectrogram (B,1,F,T).
         Returns the loss as a 1-element device tensor (no host sync)."""
@@ -118,6 +160,8 @@ class TrainStep:
             x = ops.mixup(x, perm_d, lam_d)
             if self.loss == "bce":
                 y = ops.mixup(y, perm_d, lam_d)
+        if self.graph and self.t >= self.graph_warmup:
+            return self._graph_step(x, y, perm_d if self.use_mixup else None, lam_d if self.use_mixup else None)
         logits, feat, ctx = passt_forward(net, x, save=True)
         gs = 1.0 / self.reducer.world
         if self.loss == "bce":
@@ -146,3 +190,47 @@ class TrainStep:
         self.t = self._t_now
         net.mark_params_updated()
         return loss
+
+    def _graph_step(self, x, y, perm_d, lam_d):
+        """x: mixed spectrogram; y: targets (BCE: already mixed f32; CE: class ids).  Host draws in the eager order, fixed-address
+        buffers refilled, ONE graph replay."""
+        net = self.net
+        y2 = None
+        if self.loss == "ce":
+            y = y.to(torch.int32)
+            if perm_d is not None:
+                y2 = y[perm_d.long()].contiguous()
+            else:
+                lam_d = None
+        else:
+            lam_d = None
+        self._t_now = self.t + 1
+        d = patchout_draws(net, x.shape)                     # the Patchout draws of this step, where passt_forward would draw them
+        g = self._g
+        if g is None or "graph" not in g:
+            if g is None:
+                g = dict(capturing=False, x=torch.empty_like(x), Np=d["Np"],
+                         pf=torch.empty(d["Np"], device=x.device, dtype=torch.int32), pt=torch.empty(d["Np"], device=x.device, dtype=torch.int32),
+                         pt_pos=torch.empty(d["Np"], device=x.device, dtype=torch.int32), y=torch.empty_like(y),
+                         y2=None if y2 is None else torch.empty_like(y2), lam=None if lam_d is None else torch.empty_like(lam_d),
+                         hyper=torch.empty(7, device=x.device, dtype=torch.float32), hyper_host=torch.empty(7, dtype=torch.float32))
+                self._g = g
+            self._graph_fill(g, d, x, y, y2, lam_d)
+            net.mark_params_updated()                        # the staged weight copies are stale: their refresh launch is captured too
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            g["capturing"] = True
+            try:
+                with torch.cuda.graph(graph):
+                    g["loss"] = self._graph_body(g)
+            finally:
+                g["capturing"] = False
+            g["graph"] = graph
+        else:
+            if d["Np"] != g["Np"] or x.shape != g["x"].shape:
+                raise RuntimeError("TrainStep(graph=True): the batch shape / number of kept patches changed since the capture")
+            self._graph_fill(g, d, x, y, y2, lam_d)
+        g["graph"].replay()
+        self.t = self._t_now
+        net.mark_params_updated()
+        return g["loss"]

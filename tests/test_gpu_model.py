@@ -393,6 +393,39 @@ def test_per_bucket_optimizer_equals_one_launch_bitwise(overlap, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("loss,T", [("bce", None), ("ce", 170)])
+def test_train_step_graph_equals_eager(loss, T):
+    """TrainStep(graph=True) -- the network's forward, the loss, the backward and the per-bucket AdamW launches captured once as a
+    hipGraph after three eager steps, then replayed with the step's host-drawn arrays (Patchout indices, positional offset,
+    mixup, AdamW scalars) refilled in fixed-address device buffers -- against the eager TrainStep on the same RNG stream: the
+    same kernels with the same arguments, so six steps leave BIT-identical parameters and moments.  The CE variant feeds clips
+    shorter than the model's time axis: a random positional offset per step rides in the uploaded index array."""
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=941)
+    x, y = G.model_inputs(case)
+    if T is not None:
+        x = x[..., :T].copy()
+    if loss == "ce":
+        y = (detgen.uniform(941, "cls", (x.shape[0],), 0.0, float(case["cfg"]["num_classes"])).astype(np.int64)) % case["cfg"]["num_classes"]
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    outs = []
+    for graph in (False, True):
+        net = build(case, "bf16").train()
+        ts = TrainStep(net, None, lr=1e-3, weight_decay=1e-2, use_mixup=True, loss=loss, graph=graph)
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(6):
+                torch.manual_seed(70 + step)
+                np.random.seed(70 + step)
+                losses.append(ts.step(xg, yg).clone())
+        torch.cuda.synchronize()
+        assert ts.t == 6 and (not graph or "graph" in ts._g)
+        outs.append((torch.cat([l.reshape(1) for l in losses]).cpu(), ts.flat_p.clone(), ts.m.clone(), ts.v.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_optim_adamw_matches_torch():
     """passt_amd.optim.AdamW (one fused pa_adamw launch over the flat gradient buffer the autograd node returns) against
     torch.optim.AdamW on an identical twin, three steps of the real drop-in path with an LR scheduler; head_dist.* (never a
