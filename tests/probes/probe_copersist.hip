@@ -24,7 +24,12 @@ __global__ __launch_bounds__(1024) void occupy(unsigned long long ticks_100mhz, 
     if (sink && lds[threadIdx.x] == 77) *sink = 1;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // argv[1]: 0 = both streams at the default priority, 1 (default) = occupier on a high-priority stream, GEMM at the lowest
+    const int prio_mode = argc > 1 ? atoi(argv[1]) : 1;
+    // argv[2], argv[3]: threads and LDS bytes of an occupier workgroup (default 1024 threads, 64 KiB: cannot share a CU with a GEMM
+    // workgroup; 64 threads and 0 bytes can)
+    const int occ_threads = argc > 2 ? atoi(argv[2]) : 1024, occ_lds = argc > 3 ? atoi(argv[3]) : 64 * 1024;
     const int M = 30336, N = 768, K = 3072;
     uint16_t *A, *W;
     float *bias, *resid, *out;
@@ -39,15 +44,25 @@ int main() {
     hipStream_t sa, sb;
     int lo, hi;
     CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, lo));
-    CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi));
+    if (prio_mode == 1) {
+        CK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, lo));
+        CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi));
+    } else if (prio_mode == 2) {         // what bench.py sets up: compute at the default priority, communication high
+        CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+        CK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi));
+    } else {
+        CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    }
+    printf("stream priorities: mode %d (range lowest %d .. highest %d)\n", prio_mode, lo, hi);
     CK(hipFuncSetAttribute((const void*)occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     pa_gemm_args a = {};
     a.dtype = PA_BF16; a.epilogue = PA_EPI_RESID; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.A = A; a.B = W; a.bias = bias;
     a.resid = resid; a.ldr = N; a.out_f32 = out; a.ldo32 = N; a.split_k = 1;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("fc2-shaped GEMM (M %d, N %d, K %d, RESID epilogue), us per launch, best of 5; occupier: R workgroups of 1024 threads + 64 KiB LDS\n", M, N, K);
+    printf("fc2-shaped GEMM (M %d, N %d, K %d, RESID epilogue), us per launch, best of 5; occupier: R workgroups of %d threads + %d bytes LDS\n", M, N, K,
+           occ_threads, occ_lds);
     printf("%6s %14s %14s\n", "R", "persistent", "one item/wg");
     for (int R : {0, 8, 16, 32, 64}) {
         float best[2] = {1e9f, 1e9f};
@@ -55,7 +70,7 @@ int main() {
             a.reserved = mode ? PA_GEMM_NO_PERSIST : 0;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipDeviceSynchronize());
-                if (R) hipLaunchKernelGGL(occupy, dim3(R), dim3(1024), 64 * 1024, sb, 100ull * 600, (int*)nullptr);      // 600 us
+                if (R) hipLaunchKernelGGL(occupy, dim3(R), dim3(occ_threads), occ_lds, sb, 100ull * 600, (int*)nullptr);      // 600 us
                 // give the occupier time to become resident before the GEMM is enqueued
                 for (volatile int spin = 0; spin < 400000; ++spin) {}
                 CK(hipEventRecord(e0, sa));
