@@ -34,6 +34,12 @@ namespace pa {
 #ifndef PA_ATTN_PRIO
 #define PA_ATTN_PRIO 0
 #endif
+// Packed f32 math on accumulator register pairs (A/B knob, round 4): the row sums of the forward as 16 v_pk_add_f32 instead of
+// 32 v_add_f32, the p * dP products of the backward as 8 v_pk_mul_f32 instead of 16 v_mul_f32 (pairs (r, r + 1), r even, are
+// 64-bit aligned in an MFMA accumulator block).
+#ifndef PA_ATTN_PK
+#define PA_ATTN_PK 0
+#endif
 static constexpr int HD = 64;       // head dim (all PaSST archs: 768/12, 1024/16, 384/6, 128/2)
 static constexpr int TROWS = 64;    // streamed rows per LDS tile
 static constexpr float LOG2E = 1.4426950408889634f;
@@ -430,6 +436,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             }
         }
         float psum = 0.f;
+#if PA_ATTN_PK
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && !both) break;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+                s[kb][r + 1] = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                ps2 += f32x2{s[kb][r], s[kb][r + 1]};
+            }
+        }
+        psum = ps2[0] + ps2[1];
+#else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && !both) break;
@@ -439,6 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 psum += s[kb][r];
             }
         }
+#endif
         l_run += psum;
         // O^T[d][q] += V^T[d][key] P^T[key][q]; the V column fragments of step i+1 are in flight under the MFMAs of step i
         constexpr int ns = both ? 2 * NSB : NSB;
@@ -582,12 +603,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
             for (int r = 0; r < 16; ++r) sa[r] = fmaf(sa[r], sl2, nl[r]);
         }
+#if PA_ATTN_PK
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 pp = {__builtin_amdgcn_exp2f(sa[r]), __builtin_amdgcn_exp2f(sa[r + 1])};
+            const f32x2 d2 = f32x2{dpa[r], dpa[r + 1]} * pp;    // dS / scale
+            sa[r] = pp[0]; sa[r + 1] = pp[1];
+            dpa[r] = d2[0]; dpa[r + 1] = d2[1];
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(sa[r]);
             sa[r] = p;
             dpa[r] *= p;                                        // dS / scale
         }
+#endif
         // queries beyond nq exist only in the last tile; lanes whose own key is beyond N only produce their own,
         // never stored, outputs and need no mask
         if (LAST && (nq & (TROWS - 1))) {
@@ -740,8 +771,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             mma32<T>(sa, row_frag_off<T>(sK, lo, kb * 32, st), qf[st]);
             mma32<T>(dpa, row_frag_off<T>(sV, lo, kb * 32, st), dof[st]);
         }
+#if PA_ATTN_PK
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 pp = {__builtin_amdgcn_exp2f(PRE ? sa[r] : fmaf(sa[r], sl2, -lse2)), __builtin_amdgcn_exp2f(PRE ? sa[r + 1] : fmaf(sa[r + 1], sl2, -lse2))};
+            const f32x2 d2 = f32x2{dpa[r], dpa[r + 1]} * pp;    // dS^T / scale
+            dpa[r] = d2[0]; dpa[r + 1] = d2[1];
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) dpa[r] *= __builtin_amdgcn_exp2f(PRE ? sa[r] : fmaf(sa[r], sl2, -lse2));      // dS^T / scale
+#endif
         if (LAST && (N & (TROWS - 1))) {                        // keys beyond N: last tile only
 #pragma unroll
             for (int r = 0; r < 16; ++r)
