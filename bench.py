@@ -101,8 +101,12 @@ def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7):
         t_last = 2.0 * (n - 1) / n * last / bw * 1e3
         bwd_window = 0.6 * ms_step_1gpu                         # the backward is ~60 % of the step
         exposed = max(0.0, t_all - t_last - bwd_window) + max(0.0, t_last - 0.4)   # 0.4 ms of optimizer work covers the tail
-        out[str(n)] = {"wire_ms": round(t_all, 3), "exposed_ms": round(exposed, 3),
-                       "efficiency": round(ms_step_1gpu / (ms_step_1gpu + exposed), 4)}
+        # while a bucket is on the wire the backward's MFMA kernels (~85 % of its time) share the CUs with the all-reduce kernels:
+        # measured on one GPU with a stand-in that holds whole CUs (profiles/r04_copersist_probe.txt): +28 % per GEMM from 8 CUs on
+        # (nothing if RCCL's workgroups fit beside ours); plus the 1.6 % the one-item-per-workgroup launch form costs the GEMMs
+        interference = 0.28 * 0.85 * min(t_all, bwd_window) + 0.016 * 0.7 * ms_step_1gpu
+        out[str(n)] = {"wire_ms": round(t_all, 3), "exposed_ms": round(exposed, 3), "interference_ms": round(interference, 3),
+                       "efficiency": round(ms_step_1gpu / (ms_step_1gpu + exposed + interference), 4)}
     return out
 
 
@@ -627,7 +631,8 @@ def run(args):
                                "per_epilogue": per_kind}
         # multi-GPU: SCALE is measured by the driver when it has an 8-GPU node; what can be said from ONE GPU is a model
         out["scaling_model"] = {"kind": "MODELLED, not measured", "inputs": "this run's ms_per_step, the reducer's bucket bytes "
-                                "(one bucket per block, launched from the backward), min(N-1, 7) xGMI links x 153 GB/s at 35 % (an ASSUMED RCCL bus efficiency)",
+                                "(one bucket per block, launched from the backward), min(N-1, 7) xGMI links x 153 GB/s at 35 % (an ASSUMED RCCL bus efficiency), "
+                                "GEMM slow-down next to a co-running whole-CU kernel from profiles/r04_copersist_probe.txt (worst case: +28 %)",
                                 "bucket_MB": {str(k): round(v / 1e6, 2) for k, v in ts.reducer.bucket_bytes().items()},
                                 "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes())}
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
