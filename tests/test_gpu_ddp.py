@@ -131,16 +131,18 @@ def _check_against_single_process(dp, ref, variant):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on the first multi-GPU box")
+@pytest.mark.parametrize("path", ["trainstep", "attach"])
 @pytest.mark.parametrize("transport", ["torch", "rccl_abi"])
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_ranks_over_rccl_equal_one_process(tmp_path, transport, wire):
+def test_ranks_over_rccl_equal_one_process(tmp_path, transport, wire, path):
     """The same comparison over the REAL wire: backend nccl (= RCCL over xGMI), one device per rank, through
     torch.distributed and through the library's own pa_comm_* entry points; 2 ranks and -- when the box has them -- 4 / 8
-    (global batch 8).  Skipped on a single-GPU box, self-verifying on the first node that has more."""
+    (global batch 8); TrainStep and the drop-in path with ddp.attach.  Skipped on a single-GPU box, self-verifying on the first
+    node that has more."""
     ref = _run(str(tmp_path / "ref.pt"), 1)
     worlds = [w for w in (2, 4, 8) if w <= torch.cuda.device_count()]
     for world in worlds:
-        extra = ("--backend", "nccl", "--transport", transport) + (("--comm-dtype", "bf16") if wire == "bf16" else ())
+        extra = ("--backend", "nccl", "--transport", transport, "--path", path) + (("--comm-dtype", "bf16") if wire == "bf16" else ())
         dp = _run(str(tmp_path / f"dp{world}.pt"), world, extra)
         assert dp["world"] == world
         _check_against_single_process(dp, ref, wire)
