@@ -53,6 +53,16 @@ BIG_CASES = {
     "model_esc50_train_full": dict(cfg=O.make_cfg(num_classes=50, s_patchout_t=10, s_patchout_f=3), B=2, T=500, training=True,
                                    seed=19, torch_seed=555, compact=True),
 }
+# r05: BASELINE config #2 EXACTLY, at the benchmarked batch (768/12/12, s_patchout t = 40 / f = 4 => 474 tokens, B = 64,
+# M = 30 336 token rows: 237 row tiles, persistent rounds, 7-slice batched weight gradients, XCD mapping) -- once on a
+# random spectrogram and once on the constant batch the reference's own speed test uses (x = ones(B,1,128,998), target =
+# ones(B,527): ex_audioset.py:384-385).  ~1.5 min of CPU each for the real reference; gradients stored compact.
+B64_CASES = {
+    "model_passt_s_train_b64": dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=64, T=998, training=True,
+                                    seed=25, torch_seed=6464, compact=True),
+    "model_passt_s_train_b64_ones": dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=64, T=998, training=True,
+                                         seed=26, torch_seed=6465, compact=True, inputs="ones"),
+}
 FRONTEND_CASES = {
     "frontend_eval": dict(B=2, L=32000, training=False, seed=21,
                           kw=dict(fmin_aug_range=10, fmax_aug_range=2000)),
@@ -67,6 +77,8 @@ FRONTEND_CASES = {
 
 def model_inputs(case):
     cfg, B, T = case["cfg"], case["B"], case["T"]
+    if case.get("inputs") == "ones":                     # model_speed_test's batch (ex_audioset.py:384-385)
+        return (np.ones((B, 1, cfg["img_size"][0], T), np.float32), np.ones((B, cfg["num_classes"]), np.float32))
     x = detgen.uniform(case["seed"], "x", (B, 1, cfg["img_size"][0], T), -1.5, 1.5)
     y = (detgen.uniform(case["seed"], "y", (B, cfg["num_classes"]), 0.0, 1.0) < 0.1).astype(np.float32)
     return x, y
@@ -222,6 +234,11 @@ if __name__ == "__main__":
     torch.set_num_threads(min(32, os.cpu_count()))
     if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the full-size cases (minutes of CPU time); big <name>: one of them
         for n, c in BIG_CASES.items():
+            if len(sys.argv) < 3 or n in sys.argv[2:]:
+                gen_model_case(n, c)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b64":       # config #2 at the benchmarked batch
+        for n, c in B64_CASES.items():
             if len(sys.argv) < 3 or n in sys.argv[2:]:
                 gen_model_case(n, c)
         sys.exit(0)

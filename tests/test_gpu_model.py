@@ -547,6 +547,64 @@ def test_full_size_model_vs_golden(golden_dir, name, precision):
     record(f"{name}[{precision}]", **metrics)
 
 
+# ---- r05: BASELINE config #2 at the benchmarked batch (B = 64, M = 30 336 token rows), reference-generated -------------
+def _check_b64_grads(named_grads, gold, precision, tag):
+    worst, worst_norm = 0.0, 0.0
+    for k, g in named_grads:
+        got, nrm = G.subsample(g.detach().cpu().numpy(), compact=True)
+        e = rel(got, gold["grad." + k])
+        en = abs(nrm - float(gold["gradnorm." + k])) / (float(gold["gradnorm." + k]) + 1e-30)
+        worst, worst_norm = max(worst, e), max(worst_norm, en)
+        assert e < (1e-3 if precision == "fp32" else BF16_GRADS), (tag, k, e)
+        assert en < (1e-3 if precision == "fp32" else BF16_GRADS), (tag, k, en)
+    return worst, worst_norm
+
+
+@pytest.mark.parametrize("name", list(G.B64_CASES))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config2_batch64_vs_reference_golden(golden_dir, name, precision):
+    """The whole network at the size bench.py times: 768/12/12, s_patchout t = 40 / f = 4 (474 tokens), B = 64 -- 237 row tiles,
+    persistent rounds, 7-slice batched weight gradients, XCD-mapped attention -- against fixtures the REAL reference produced on
+    CPU (make_golden.py b64), on a random spectrogram and on model_speed_test's constant batch (ex_audioset.py:384-385).  Both
+    product paths: the autograd node (logits, features, loss, every gradient) and TrainStep(use_mixup=False) (loss and every
+    gradient of its flat buffer; lr = 0 so the per-bucket optimizer leaves the parameters alone)."""
+    case = G.B64_CASES[name]
+    gold = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    ltol = 1e-5 if precision == "fp32" else 2e-3
+    # (a) drop-in path
+    m = build(case, precision).train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(case["torch_seed"])
+        logits, feat = m(xg)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, yg, reduction="none").mean()
+        loss.backward()
+    e_l, e_f = rel(logits.detach().cpu(), gold["logits"]), rel(feat.detach().cpu(), gold["features"])
+    lim = 1e-3 if precision == "fp32" else BF16_LOGITS
+    assert e_l < lim and e_f < lim, (e_l, e_f)
+    assert abs(loss.item() - float(gold["loss"])) < ltol
+    for k, p in m.named_parameters():
+        if "gradnone." + k in gold:
+            assert p.grad is None, k
+    w_a, wn_a = _check_b64_grads([(k, p.grad) for k, p in m.named_parameters() if "grad." + k in gold], gold, precision, "autograd")
+    del m, logits, feat, loss
+    # (b) TrainStep: same draws (same torch seed, same call order), no mixup, lr = 0
+    from passt_amd.train import TrainStep
+    m = build(case, precision).train()
+    ts = TrainStep(m, mel=None, lr=0.0, weight_decay=0.0, use_mixup=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(case["torch_seed"])
+        loss_t = ts.step(xg, yg)
+    assert abs(float(loss_t.item()) - float(gold["loss"])) < ltol
+    w_t, wn_t = _check_b64_grads([(k, ts.grads[k]) for k, _ in ts.named], gold, precision, "trainstep")
+    ts.close()
+    record(f"{name}[{precision}]", logits=e_l, features=e_f, worst_grad_autograd=w_a, worst_grad_norm_autograd=wn_a,
+           worst_grad_trainstep=w_t, worst_grad_norm_trainstep=wn_t)
+
+
 def test_ensemble_and_other_strides_eval():
     """get_ensemble_model (models/passt.py:1021-1045): mean of the member logits; members with stride 10 and stride 14
     (different patch grids: 12x99 and 9x71) each against the oracle."""

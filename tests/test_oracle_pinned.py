@@ -79,6 +79,27 @@ def test_full_size_oracle_vs_golden(golden_dir, name):
             assert abs(got_nrm - nrm) <= 2e-4 * nrm + 1e-9, k
 
 
+@pytest.mark.parametrize("name", list(G.B64_CASES))
+def test_config2_batch64_oracle_vs_golden(golden_dir, name):
+    """The oracle at BASELINE config #2's own batch (B = 64, 474 tokens, depth 12) against the fixtures the real reference
+    produced at that size (random input; model_speed_test's constant batch)."""
+    case = G.B64_CASES[name]
+    gold = _load(golden_dir, name)
+    sd, logits, feat, loss = _oracle_model_case(case)
+    np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], atol=5e-5, rtol=2e-4)
+    np.testing.assert_allclose(feat.detach().numpy(), gold["features"], atol=5e-5, rtol=2e-4)
+    assert abs(loss.item() - float(gold["loss"])) < 1e-6
+    for k, p in sd.items():
+        if "gradnone." + k in gold:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref, nrm = gold["grad." + k], float(gold["gradnorm." + k])
+        got, got_nrm = G.subsample(p.grad.numpy(), compact=True)
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert np.abs(got - ref).max() <= 5e-4 * scale + 1e-9, k
+        assert abs(got_nrm - nrm) <= 2e-4 * nrm + 1e-9, k
+
+
 def test_patchout_indices_bit_exact(golden_dir):
     """patchout indices must be bit-exact (north_star): replay the torch CPU RNG draws."""
     for name, case in G.CASES.items():
