@@ -86,7 +86,7 @@ def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
     return 3 * fwd / 1e9
 
 
-def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7):
+def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7, bus_eff=0.35):
     """MODELLED (not measured) weak-scaling curve for N = 2, 4, 8 GPUs of one node from the measured single-GPU step and
     the measured per-bucket wire bytes: ring all-reduce of S bytes moves 2 (N-1)/N S per GPU; xGMI is point-to-point,
     a ring uses one link per direction, RCCL runs one ring per link it can (min(N-1, links) of 153 GB/s each).  Every
@@ -96,7 +96,9 @@ def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7):
     total, last = sum(sizes), sizes[-1] + (sizes[-2] if len(sizes) > 1 else 0)     # block 0 and patch-embedding buckets
     out = {}
     for n in (2, 4, 8):
-        bw = min(n - 1, links) * link_gbps * 1e9 * 0.35         # RCCL's large-message bus bandwidth is ~1/3 of the aggregate link peak
+        # bus_eff: RCCL's large-message bus bandwidth as a fraction of the aggregate link peak -- 0.35 is an ASSUMPTION; an N > 1
+        # run replaces it with what its own idle all-reduce of these buckets measured (allreduce_measured.idle.bus_GBps_total)
+        bw = min(n - 1, links) * link_gbps * 1e9 * bus_eff
         t_all = 2.0 * (n - 1) / n * total / bw * 1e3            # ms on the wire per step
         t_last = 2.0 * (n - 1) / n * last / bw * 1e3
         bwd_window = 0.6 * ms_step_1gpu                         # the backward is ~60 % of the step
@@ -200,9 +202,18 @@ class AutogradStep:
     Lightning's precision=16 does.  N > 1: passt_amd.ddp.attach(net) -- the node all-reduces per-block buckets from inside
     its backward (no DistributedDataParallel wrapper).  Same .step(x, y) / .reducer / .close() surface as TrainStep."""
 
-    def __init__(self, net, mel, lr, weight_decay, loss, mixup_alpha, precision, comm_dtype, transport, optimizer="adamw"):
+    def __init__(self, net, mel, lr, weight_decay, loss, mixup_alpha, precision, comm_dtype, transport, optimizer="adamw", mixup="ref"):
         from passt_amd import ddp
         self.net, self.mel, self.loss, self.alpha = net, mel, loss, mixup_alpha
+        if mixup == "pa":
+            from passt_amd.mixup import my_mixup                    # the one-word import change (results already on the device)
+        else:
+            def my_mixup(size, alpha):                              # helpers/mixup.py:5-12 as is: CPU permutation, CPU lam
+                rn_indices = torch.randperm(size)
+                lambd = np.random.beta(alpha, alpha, size).astype(np.float32)
+                lambd = np.concatenate([lambd[:, None], 1 - lambd[:, None]], 1).max(1)
+                return rn_indices, torch.FloatTensor(lambd)
+        self.my_mixup = my_mixup
         self.autocast = precision == "bf16"
         self.phases = {} if os.environ.get("PASST_AMD_BENCH_PHASES") == "1" else None
         self._mark = None
@@ -248,10 +259,9 @@ class AutogradStep:
             x = x.reshape(old_shape[0], old_shape[1], x.shape[1], x.shape[2])
         mark("mel")
         B = len(y)
-        perm = torch.randperm(B)
-        lam = np.random.beta(self.alpha, self.alpha, B).astype(np.float32)
-        lam = torch.from_numpy(np.maximum(lam, 1.0 - lam)).to(x.device)
-        x = x * lam.reshape(B, 1, 1, 1) + x[perm] * (1.0 - lam.reshape(B, 1, 1, 1))
+        perm, lam = self.my_mixup(B, self.alpha)                                              # ex_audioset.py:173
+        lam = lam.to(x.device)                                                                # :174
+        x = x * lam.reshape(B, 1, 1, 1) + x[perm] * (1.0 - lam.reshape(B, 1, 1, 1))          # :175-176
         mark("mixup")
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             y_hat, _ = net(x)
@@ -276,6 +286,83 @@ class AutogradStep:
             n = max(self.phases.pop("steps", 1), 1)
             print("autograd step phases (ms, device synchronised between them): "
                   + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in self.phases.items()), file=sys.stderr, flush=True)
+
+
+def speed_test_flow(net, batch_size, warmup=10, test_length=100, compile_net=True, spectrogram="ones"):
+    """The reference's ``model_speed_test`` (ex_audioset.py:364-426), statement for statement, around ``net``:
+    x = ones(B,1,128,998), target = ones(B,527) (:384-385), GradScaler (:389), ``torch.compile(net)`` (:391),
+    SGD(lr=0.001) over the compiled module's parameters (:392), 10 warm-up + 100 timed iterations of
+    autocast (fp16, ``torch.cuda.amp.autocast()``'s default) -> net -> BCE mean -> scaler.scale(loss).backward() ->
+    scaler.step -> scaler.update (:398-404, :413-419), device-synchronised wall clock (:405-406, :420-421).  No zero_grad --
+    the reference has none either: gradients accumulate into .grad across iterations (the autograd node's fresh gradient is
+    added to the kept one by AccumulateGrad), which this flow therefore pays for like the reference does.
+    Returns specs/second and what the scaler / compiler did."""
+    import torch.nn.functional as F
+    from torch._dynamo.utils import counters
+    dev = next(net.parameters()).device
+    x = torch.ones([batch_size, 1, 128, 998], device=dev) if spectrogram == "ones" else torch.randn([batch_size, 1, 128, 998], device=dev)
+    target = torch.ones([batch_size, 527], device=dev)
+    scaler = torch.cuda.amp.GradScaler()
+    counters.clear()
+    if compile_net:
+        net = torch.compile(net)
+    optimizer = torch.optim.SGD(net.parameters(), lr=0.001)
+
+    def one():
+        with torch.cuda.amp.autocast():
+            y_hat, embed = net(x)
+            loss = F.binary_cross_entropy_with_logits(y_hat, target, reduction="none").mean()
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        return loss, y_hat
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(warmup):
+            loss, y_hat = one()
+        torch.cuda.synchronize()
+        t_warm = time.time() - t1
+        frames_after_warmup = counters["frames"].get("total", 0)
+        first_loss = float(loss.item())
+        t1 = time.time()
+        for _ in range(test_length):
+            loss, y_hat = one()
+        torch.cuda.synchronize()
+        t2 = time.time()
+    return {"specs_per_second": test_length * batch_size / (t2 - t1), "ms_per_iteration": 1e3 * (t2 - t1) / test_length,
+            "warmup_s": t_warm, "first_loss": first_loss, "last_loss": float(loss.item()), "logits_dtype": str(y_hat.dtype),
+            "grad_scale": float(scaler.get_scale()),
+            "dynamo": {"graphs_captured": counters["stats"].get("unique_graphs", 0), "frames_after_warmup": frames_after_warmup,
+                       "frames_total": counters["frames"].get("total", 0)}}
+
+
+def run_speed_test(args):
+    """`bench.py --speedtest`: the reference's own definition of its speed metric, one JSON line per batch size."""
+    import passt_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    for B in ([args.batch] if args.batch else [64, 12]):          # BASELINE config #2's batch; the reference's default (:365)
+        torch.manual_seed(1234)
+        with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
+            warnings.simplefilter("ignore")
+            net = passt_amd.get_model(arch=ARCH, pretrained=False, n_classes=527, s_patchout_t=40, s_patchout_f=4).to(dev).train()
+        r = speed_test_flow(net, B, warmup=max(args.warmup, 1), test_length=args.steps, compile_net=not args.no_compile)
+        gflop = algorithmic_gflop_per_clip()
+        print(json.dumps({"metric": "specs/second, model_speed_test (ex_audioset.py:364-426): torch.compile(net) + fp16 autocast + "
+                                    "GradScaler + SGD, x = ones(B,1,128,998), target = ones(B,527)",
+                          "value": round(r["specs_per_second"], 1), "unit": "specs/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": max(args.warmup, 1), "ms_per_step": round(r["ms_per_iteration"], 3), "higher_is_better": True,
+                          "dtype": "bf16 MFMA under the caller's fp16 autocast (f32 logits / gradients)", "data": "synthetic",
+                          "config": {"workload": "passt_s (768/12/12, s_patchout_t=40,f=4: 474 tokens), net only (no mel, no mixup), "
+                                                 "drop-in autograd path, torch.optim.SGD, no zero_grad (as the reference)",
+                                     "per_gpu_batch": B, "compiled": not args.no_compile},
+                          "mfma_frac_end_to_end": round(r["specs_per_second"] * gflop / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
+                          "first_loss": round(r["first_loss"], 6), "last_loss": round(r["last_loss"], 6),
+                          "grad_scale_after": r["grad_scale"], "dynamo": r["dynamo"], "logits_dtype": r["logits_dtype"]}), flush=True)
+        del net
 
 
 def error_line(args, msg, **extra):
@@ -357,6 +444,40 @@ def self_launch(args):
     return 0
 
 
+def sweep(args):
+    """`--sweep-gpus 1,2,4,8`: one child `python bench.py --gpus N ...` per N, in turn (each self-launches its ranks); every child's
+    ONE JSON line is passed through as it arrives, so a single command yields the weak-scaling curve (per-GPU batch fixed) with
+    the rank / communicator evidence in each N > 1 line.  Efficiency is the reader's to compute (value_N / (N * value_1)).
+    Returns non-zero if any N failed (its error line is still printed)."""
+    import subprocess
+    try:
+        ns = [int(t) for t in args.sweep_gpus.split(",") if t.strip()]
+        assert ns and all(n >= 1 for n in ns)
+    except (ValueError, AssertionError):
+        error_line(args, f"--sweep-gpus wants a comma-separated list of GPU counts, got {args.sweep_gpus!r}")
+        return 2
+    argv, skip = [], False
+    for a in sys.argv[1:]:                         # this command line without --sweep-gpus / --gpus
+        if skip:
+            skip = False
+        elif a in ("--sweep-gpus", "--gpus"):
+            skip = True
+        elif not a.startswith(("--sweep-gpus=", "--gpus=")):
+            argv.append(a)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    worst = 0
+    for n in ns:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + argv, env=env, stdout=subprocess.PIPE)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if len(lines) == 1:
+            print(lines[0], flush=True)
+        else:
+            args.gpus = n
+            error_line(args, f"the --gpus {n} child printed {len(lines)} JSON lines (rc {r.returncode})")
+        worst = max(worst, abs(r.returncode))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,8 +506,29 @@ def main():
                          "UNMODIFIED ex_audioset.py runs -- mel -> torch mixup -> net(x) (one autograd Function) -> torch BCE -> "
                          "loss.backward() -> torch.optim.AdamW, gradients all-reduced per block from inside the backward "
                          "(passt_amd.ddp.attach)")
+    ap.add_argument("--sweep-gpus", default="",
+                    help="comma-separated GPU counts, e.g. 1,2,4,8: runs this same command once per N (self-launching each, one "
+                         "after the other) and prints ONE JSON line per N -- the whole weak-scaling curve from one command on an "
+                         "8-GPU node; the N = 1 line is the BENCH configuration")
+    ap.add_argument("--mixup", default="ref", choices=["ref", "pa"],
+                    help="--path autograd: ref = helpers/mixup.py's my_mixup as is (CPU results: three synchronising copies per step); "
+                         "pa = passt_amd.mixup.my_mixup, the one-word import change (same draws, results already on the device)")
+    ap.add_argument("--speedtest", action="store_true",
+                    help="the reference's model_speed_test flow (ex_audioset.py:364-426) around passt_amd's module: torch.compile + "
+                         "fp16 autocast + GradScaler + SGD on x = ones(B,1,128,998); one line per batch (64 and 12, or --batch)")
+    ap.add_argument("--no-compile", action="store_true", help="--speedtest without torch.compile(net) (A/B)")
     args = ap.parse_args()
 
+    if args.sweep_gpus:
+        sys.exit(sweep(args))
+    if args.speedtest:
+        if not torch.cuda.is_available():
+            error_line(args, "no HIP device visible (passt_amd has no CPU path)", devices_visible=0)
+            sys.exit(2)
+        if args.steps == 20 and args.warmup == 5:
+            args.steps, args.warmup = 100, 10                 # the reference's test_length / warm-up (:381, :397)
+        run_speed_test(args)
+        return
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         if args.gpus > 1:
             sys.exit(self_launch(args))
@@ -456,7 +598,7 @@ def run(args):
     # TrainStep / ddp.attach broadcast rank 0's parameters themselves (identical replicas)
     if args.path == "autograd":
         ts = AutogradStep(net, mel, lr=2e-5, weight_decay=1e-4, loss=cfgd["loss"], mixup_alpha=0.3, precision=args.precision,
-                          comm_dtype=args.comm_dtype, transport=args.transport, optimizer=args.optimizer)
+                          comm_dtype=args.comm_dtype, transport=args.transport, optimizer=args.optimizer, mixup=args.mixup)
     else:
         ts = TrainStep(net, mel, lr=2e-5, weight_decay=1e-4, optimizer=args.optimizer, mixup_alpha=0.3, use_mixup=True,
                        loss=cfgd["loss"], comm_dtype=args.comm_dtype, transport=args.transport, graph=args.graph)
@@ -557,6 +699,9 @@ def run(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            **({"allreduce_bus_GBps_idle": allreduce["idle"]["bus_GBps_total"],
+                "allreduce_exposed_wait_ms_per_step": allreduce["exposed_wait_ms_per_step"],
+                "rccl_nranks": rccl.get("nranks")} if allreduce is not None else {}),
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
@@ -565,6 +710,7 @@ def run(args):
                                 if args.path == "trainstep" else
                                 "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
                                 + {"adamw": "AdamW (multi-tensor default)", "sgd": "SGD", "pa_adamw": "AdamW replaced by passt_amd.optim.AdamW"}[args.optimizer]
+                                + (", my_mixup replaced by passt_amd.mixup.my_mixup" if args.mixup == "pa" else "")
                                 + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
                        "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
                                        if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
@@ -630,11 +776,19 @@ def run(args):
                                "gemm_time_share_of_step": round(tot_ms / n_prof_steps / ms_step, 4),
                                "per_epilogue": per_kind}
         # multi-GPU: SCALE is measured by the driver when it has an 8-GPU node; what can be said from ONE GPU is a model
-        out["scaling_model"] = {"kind": "MODELLED, not measured", "inputs": "this run's ms_per_step, the reducer's bucket bytes "
-                                "(one bucket per block, launched from the backward), min(N-1, 7) xGMI links x 153 GB/s at 35 % (an ASSUMED RCCL bus efficiency), "
-                                "GEMM slow-down next to a co-running whole-CU kernel from profiles/r04_copersist_probe.txt (worst case: +28 %)",
+        bus_eff, bus_src = 0.35, "35 % (an ASSUMED RCCL bus efficiency: no N > 1 measurement in this run)"
+        idle_bus = (allreduce or {}).get("idle", {}).get("bus_GBps_total") if not dry else None
+        if idle_bus:
+            bus_eff = idle_bus / (min(world - 1, 7) * 153.0)
+            bus_src = (f"{100 * bus_eff:.1f} % = this run's own idle all-reduce of the same buckets ({idle_bus} GB/s bus bandwidth at "
+                       f"N = {world}, allreduce_measured.idle) over the link peak")
+        out["scaling_model"] = {"kind": "MODELLED, not measured" + (" (wire term from this run's measured bus bandwidth)" if idle_bus else ""),
+                                "inputs": "this run's ms_per_step, the reducer's bucket bytes (one bucket per block, launched from the "
+                                f"backward), min(N-1, 7) xGMI links x 153 GB/s at {bus_src}, GEMM slow-down next to a co-running "
+                                "whole-CU kernel from profiles/r04_copersist_probe.txt (worst case: +28 %)",
+                                "bus_efficiency": round(bus_eff, 4),
                                 "bucket_MB": {str(k): round(v / 1e6, 2) for k, v in ts.reducer.bucket_bytes().items()},
-                                "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes())}
+                                "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes(), bus_eff=bus_eff)}
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_forward"] = cpu_baseline_forward()

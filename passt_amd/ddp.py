@@ -95,8 +95,11 @@ class RcclAbiTransport:
 
     def __del__(self):
         # never tear a communicator down from the garbage collector (peers may already have exited: ncclCommDestroy would
-        # hang); owners call close() -- TrainStep.close(), ddp.detach()
-        pass
+        # hang); owners call close() -- TrainStep.close(), ddp.detach().  A communicator still open here is a leak: say so.
+        if getattr(self, "comm", None) is not None:
+            import warnings
+            warnings.warn("passt_amd.ddp: an RCCL communicator (C-ABI transport) was garbage-collected without close() -- call "
+                          "TrainStep.close() / ddp.detach(net); the communicator and its stream stay allocated", ResourceWarning)
 
 
 class GradReducer:
@@ -330,7 +333,9 @@ def attach(net, process_group=None, comm_dtype="fp32", transport="torch", broadc
         import os
         if os.environ.get("PASST_AMD_DDP_PERSISTENT") != "1":
             from . import _lib
-            object.__setattr__(net, "_gemm_flags", _lib.GEMM_NO_PERSIST)
+            # OR the bit in (a TrainStep or an A/B knob may have set others) and remember that WE set it, for detach()
+            red._set_no_persist = not (getattr(net, "_gemm_flags", 0) & _lib.GEMM_NO_PERSIST)
+            object.__setattr__(net, "_gemm_flags", getattr(net, "_gemm_flags", 0) | _lib.GEMM_NO_PERSIST)
     return red
 
 
@@ -340,4 +345,7 @@ def detach(net):
         red.wait()
         red.close()
     object.__setattr__(net, "_ddp", None)
-    object.__setattr__(net, "_gemm_flags", 0)
+    if red is not None and getattr(red, "_set_no_persist", False):
+        from . import _lib
+        object.__setattr__(net, "_gemm_flags", getattr(net, "_gemm_flags", 0) & ~_lib.GEMM_NO_PERSIST)
+        red._set_no_persist = False

@@ -1,0 +1,42 @@
+"""``my_mixup`` for the drop-in (autograd) path: the reference's function with its results already on the device.
+
+The reference (helpers/mixup.py:5-12) returns a CPU permutation and a CPU ``lam``; its callers then do three synchronising
+pageable host->device copies per training step (ex_audioset.py:171-183, ex_esc50.py:152-161)::
+
+    rn_indices, lam = my_mixup(batch_size, self.mixup_alpha)
+    lam = lam.to(x.device)                                  # pageable H2D copy, host waits
+    x = x * lam.reshape(...) + x[rn_indices] * (1. - ...)   # index tensor uploaded, host waits
+    ...
+    y_mix = y * ... + y[rn_indices] * ...                   # index tensor uploaded AGAIN, after the forward was enqueued
+
+Each of them leaves the GPU idle while the host restarts (0.7-1.7 ms per step measured on MI355X,
+profiles/r04_autograd_vs_trainstep.md).  The replacement is a one-word import change::
+
+    -from helpers.mixup import my_mixup
+    +from passt_amd.mixup import my_mixup
+
+Same signature for the existing call sites, the same RNG calls in the same order (``torch.randperm(size)`` on torch's CPU
+generator, then ``np.random.beta(alpha, alpha, size)``), the same values bit for bit (tests/test_caller_flow_cpu.py pins them to
+the live reference function) -- but both results are device tensors uploaded through the library's page-locked staging ring
+(asynchronous copies): ``lam.to(x.device)`` is then a no-op and ``x[rn_indices]`` / ``y[rn_indices]`` index with a device
+tensor, so the step has no host synchronisation left.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def my_mixup(size, alpha, device=None):
+    """helpers/mixup.py:5-12.  ``device``: where the results go; None = the current HIP device when one is visible (one process
+    per GPU: the device Lightning / the caller selected), else the CPU -- then this IS the reference function."""
+    rn_indices = torch.randperm(size)                                               # :6
+    lambd = np.random.beta(alpha, alpha, size).astype(np.float32)                   # :7
+    lambd = np.concatenate([lambd[:, None], 1 - lambd[:, None]], 1).max(1)          # :8
+    lam = torch.from_numpy(lambd)                                                   # :9  (torch.FloatTensor(lambd))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    if device.type == "cpu":
+        return rn_indices, lam
+    return ops.upload_small(rn_indices, device), ops.upload_small(lam, device)

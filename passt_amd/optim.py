@@ -8,7 +8,8 @@ profiles/r04_autograd_vs_trainstep.md).  ``passt_amd.optim.AdamW`` is the one-wo
     -        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
     +        return passt_amd.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
 
-Same arithmetic as torch's (decoupled weight decay, bias corrections, eps outside the square root), same constructor
+Same arithmetic as torch's (decoupled weight decay, bias corrections from a PER-PARAMETER step count, eps outside the square
+root), same constructor
 arguments, ``param_groups`` (LR schedulers keep working: ``group["lr"]`` is read every step), ``state_dict`` layout
 ({"step", "exp_avg", "exp_avg_sq"} per parameter).  Parameters and both moments of a group live in flat f32 buffers
 (``p.data`` becomes a view, like TrainStep's); every step issues ONE ``pa_adamw`` launch per run of parameters whose
@@ -57,7 +58,7 @@ class AdamW(torch.optim.Optimizer):
         flat_p = torch.empty(total, device=dev, dtype=torch.float32)
         m = torch.zeros(total, device=dev, dtype=torch.float32)
         v = torch.zeros(total, device=dev, dtype=torch.float32)
-        offs, off, step0 = [], 0, 0
+        offs, off, steps = [], 0, []
         for p in ps:
             n = p.numel()
             flat_p[off:off + n].copy_(p.data.reshape(-1))
@@ -66,13 +67,13 @@ class AdamW(torch.optim.Optimizer):
             if st:                 # moments that already exist (re-layout, load_state_dict) move into the flat buffers
                 m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                 v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-                step0 = max(step0, int(st["step"]))
+            steps.append(int(st["step"]) if st else 0)     # PER PARAMETER, as torch counts them (state[p]["step"])
             offs.append(off)
             off += n
-        fl = self._flat[gi] = dict(ids=[id(p) for p in ps], flat_p=flat_p, m=m, v=v, offs=offs, step=step0)
-        for p, o in zip(ps, offs):
+        fl = self._flat[gi] = dict(ids=[id(p) for p in ps], flat_p=flat_p, m=m, v=v, offs=offs, steps=steps)
+        for p, o, t in zip(ps, offs, steps):
             if self.state.get(p):                       # existing per-parameter state now views the flat moments
-                self._bind_state(fl, p, o, step0)
+                self._bind_state(fl, p, o, t)
         return fl, ps
 
     def _bind_state(self, fl, p, off, step):
@@ -99,9 +100,7 @@ class AdamW(torch.optim.Optimizer):
                 continue
             fl, ps = self._ensure_flat(gi, group)
             (b1, b2), lr, eps, wd = group["betas"], float(group["lr"]), group["eps"], group["weight_decay"]
-            fl["step"] += 1
-            t = fl["step"]
-            offs = fl["offs"]
+            offs, steps = fl["offs"], fl["steps"]
             # runs of consecutive parameters whose gradients are dense f32 and adjacent in memory: one launch each
             i, n_p = 0, len(ps)
             while i < n_p:
@@ -118,12 +117,15 @@ class AdamW(torch.optim.Optimizer):
                 j = i + 1
                 while j < n_p:
                     gj = ps[j].grad
+                    # adjacent AND one allocation AND the same step count: the bias corrections are per parameter (a parameter
+                    # whose first gradient arrives later -- unfrozen layer -- starts at step 1 like torch's, not at the group's)
                     if (gj is None or gj.dtype != torch.float32 or not gj.is_contiguous() or gj.data_ptr() != gptr + 4 * (end - start)
-                            or gj.untyped_storage().data_ptr() != g.untyped_storage().data_ptr()):     # adjacent AND one allocation
+                            or gj.untyped_storage().data_ptr() != g.untyped_storage().data_ptr() or steps[j] != steps[i]):
                         break
                     end += ps[j].numel()
                     j += 1
                 n = end - start
+                t = steps[i] + 1
                 # one flat view over the run's gradients (adjacent views of one allocation: as_strided from the first)
                 gflat = g.as_strided((n,), (1,)) if j > i + 1 else g.reshape(-1)
                 self._launch(fl["flat_p"][start:end], gflat, fl["m"][start:end], fl["v"][start:end], lr, b1, b2, eps, wd, t)
@@ -132,6 +134,7 @@ class AdamW(torch.optim.Optimizer):
                     if "exp_avg" not in st:
                         st = self._bind_state(fl, ps[k], offs[k], t)
                     st["step"].fill_(float(t))
+                    steps[k] = t
                     torch.autograd.graph.increment_version(ps[k])      # raw-pointer update: consumers key on _version
                 i = j
         return loss

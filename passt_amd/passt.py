@@ -532,6 +532,21 @@ class _PasstFunction(torch.autograd.Function):
         return tuple(out)
 
 
+# Every registration of a parameter or sub-module on ANY nn.Module bumps this counter (torch's global registration hooks: an
+# integer increment each): PaSST._graph_params() keys its cached parameter list on it, so surgery anywhere in the tree
+# (net.head[1] = nn.Linear(768, 50), replacing a block's sub-module) is seen by the next forward without re-walking
+# named_parameters() on every call.
+_TREE_EPOCH = [0]
+
+
+def _bump_tree_epoch(*_a):
+    _TREE_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_tree_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_tree_epoch)
+
+
 class PaSST(nn.Module):
     """Same constructor as the reference (models/passt.py:391-395)."""
 
@@ -610,13 +625,13 @@ class PaSST(nn.Module):
     def _graph_params(self):
         """([(name, parameter)] without head_dist.*, total numel): what the autograd node takes and returns gradients for, in
         named_parameters() order.  Cached (walking the module tree costs 0.4 ms per call, twice per step); dropped whenever a
-        parameter or sub-module is assigned on this module or the module is moved / cast (``_apply``).  After surgery deeper
-        in the tree (replacing a sub-module of a block) call ``model._reset_runtime()``."""
+        parameter or sub-module is registered on any module (``_TREE_EPOCH``: surgery anywhere in the tree, e.g.
+        ``net.head[1] = nn.Linear(768, 50)``) or the module is moved / cast (``_apply``)."""
         hit = self._scratch.get("graph_params")
-        if hit is None:
+        if hit is None or hit[2] != _TREE_EPOCH[0]:
             named = [(n, p) for n, p in self.named_parameters() if not n.startswith("head_dist.")]
-            hit = self._scratch["graph_params"] = (named, sum(p.numel() for _, p in named))
-        return hit
+            hit = self._scratch["graph_params"] = (named, sum(p.numel() for _, p in named), _TREE_EPOCH[0])
+        return hit[:2]
 
     def __setattr__(self, name, value):
         if isinstance(value, (nn.Module, nn.Parameter)) and "_scratch" in self.__dict__:
@@ -668,8 +683,17 @@ class PaSST(nn.Module):
         """Call after updating parameters through raw device pointers (passt_amd.optim does)."""
         self._staged.epoch += 1
 
+    @torch.compiler.disable
     def forward(self, x):
-        """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595)."""
+        """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595).
+
+        ``torch.compile(net)`` (ex_audioset.py:135, model_speed_test :391): the whole forward is ONE opaque call to the
+        compiler (``torch.compiler.disable``) -- there is nothing for Inductor to fuse, every kernel of the network is already
+        a hand-written launch behind the C ABI, and dynamo cannot trace ctypes calls; the compiled module therefore runs this
+        function eagerly, captures no graph and never recompiles (tests/test_abi_cpu.py, tests/test_gpu_model.py speed-test
+        flow).  Under ``torch.autocast`` of either 16-bit type (Lightning precision=16 / torch.cuda.amp.autocast() are fp16) the
+        kernels run the bf16 MFMA path with f32 accumulation and return f32 logits / features: bf16 has f32's exponent range,
+        so a GradScaler's loss scale flows through the backward without overflow and its inf checks never fire."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # head_dist.* is not part of the graph -- as in the reference, whose forward never touches it
             # (models/passt.py:583-595; hence find_unused_parameters=True under torch DDP there and here)

@@ -85,6 +85,7 @@ class AugmentMelSTFT(nn.Module):
         self.register_buffer("_bin_mel", bin_mel.float(), persistent=False)
         self.register_buffer("_twiddle", tw.float().contiguous(), persistent=False)
 
+    @torch.compiler.disable          # one hand-written launch: opaque to torch.compile (the reference compiles only the net anyway)
     def forward(self, x):
         if not x.is_cuda:
             raise PasstAmdError("passt_amd.AugmentMelSTFT runs on a HIP device only (no CPU fallback)")

@@ -65,6 +65,9 @@ class TrainStep:
             object.__setattr__(net, "_gemm_flags", getattr(net, "_gemm_flags", 0) | ops._lib.GEMM_NO_PERSIST)
             self._set_no_persist = True
         self.graph = bool(graph) and self.reducer.world == 1
+        if self.graph and optimizer != "adamw":
+            raise NotImplementedError("TrainStep(graph=True) captures the per-bucket AdamW launches (pa_adamw_dev reads its scalars "
+                                      "from device memory); optimizer='sgd' has no such form: use graph=False")
         self.graph_warmup, self._g = 3, None
         self.t = self._t_now = 0
         self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
@@ -160,7 +163,7 @@ class TrainStep:
             x = ops.mixup(x, perm_d, lam_d)
             if self.loss == "bce":
                 y = ops.mixup(y, perm_d, lam_d)
-        if self.graph and self.t >= self.graph_warmup:
+        if self.graph and self.t >= self.graph_warmup and self._graph_fits(x):
             return self._graph_step(x, y, perm_d if self.use_mixup else None, lam_d if self.use_mixup else None)
         logits, feat, ctx = passt_forward(net, x, save=True)
         gs = 1.0 / self.reducer.world
@@ -190,6 +193,14 @@ class TrainStep:
         self.t = self._t_now
         net.mark_params_updated()
         return loss
+
+    def _graph_fits(self, x):
+        """The captured graph replays ONE batch shape.  The reference's loaders never set drop_last, so the last batch of an epoch
+        is smaller (and variable-length clips change the frame count): such a step runs the eager kernel sequence instead --
+        same kernels, same results, decided here before any of the step's random draws is consumed (the number of kept patches
+        follows from the shape alone).  The graph stays valid for the next full batch."""
+        g = self._g
+        return g is None or "graph" not in g or tuple(x.shape) == tuple(g["x"].shape)
 
     def _graph_step(self, x, y, perm_d, lam_d):
         """x: mixed spectrogram; y: targets (BCE: already mixed f32; CE: class ids).  Host draws in the eager order, fixed-address
@@ -227,10 +238,12 @@ class TrainStep:
                 g["capturing"] = False
             g["graph"] = graph
         else:
-            if d["Np"] != g["Np"] or x.shape != g["x"].shape:
-                raise RuntimeError("TrainStep(graph=True): the batch shape / number of kept patches changed since the capture")
+            # _graph_fits() routed every other shape to the eager path before the draws; the kept-patch count follows from the shape
+            assert d["Np"] == g["Np"] and x.shape == g["x"].shape
             self._graph_fill(g, d, x, y, y2, lam_d)
         g["graph"].replay()
         self.t = self._t_now
         net.mark_params_updated()
-        return g["loss"]
+        # a fresh tensor per step, like the eager path: the next replay overwrites the captured one, and callers collect losses
+        # lazily (append now, .item() later)
+        return g["loss"].clone()

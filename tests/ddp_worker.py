@@ -133,8 +133,10 @@ def main():
         dist.all_gather_object(flags, (same, losses))
     else:
         flags = [(True, losses)]
+    red = getattr(ts, "reducer", None) or getattr(ts, "red", None)
+    comm = red.comm_info() if (red is not None and world > 1) else None       # what the communicator itself reports (pa_comm_info)
     if rank == 0:
-        torch.save({"params": ts.flat_p.cpu(), "init": init.cpu(), "flags": flags, "world": world}, args.out)
+        torch.save({"params": ts.flat_p.cpu(), "init": init.cpu(), "flags": flags, "world": world, "comm_info": comm}, args.out)
     ts.close()
     if world > 1:
         import torch.distributed as dist

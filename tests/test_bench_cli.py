@@ -34,3 +34,16 @@ def test_bench_world_size_mismatch_is_reported():
     assert r.returncode != 0
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1 and "WORLD_SIZE" in json.loads(lines[0])["error"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")
+def test_bench_sweep_prints_one_line_per_gpu_count():
+    """`--sweep-gpus 1,2,4,8`: one child per N, one JSON line per N in order (here: error lines, no device) and a non-zero exit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep-gpus", "1,2,4,8", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, timeout=600)
+    assert r.returncode != 0
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert [d["n_gpus"] for d in lines] == [1, 2, 4, 8] and all(d["value"] is None and "error" in d and d["steps"] == 3 for d in lines)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep-gpus", "1,x"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 2 and "comma-separated" in json.loads(r.stdout.decode().strip().splitlines()[-1])["error"]

@@ -145,6 +145,10 @@ def test_ranks_over_rccl_equal_one_process(tmp_path, transport, wire, path):
         extra = ("--backend", "nccl", "--transport", transport, "--path", path) + (("--comm-dtype", "bf16") if wire == "bf16" else ())
         dp = _run(str(tmp_path / f"dp{world}.pt"), world, extra)
         assert dp["world"] == world
+        # the communicator itself spans `world` devices: ncclCommCount through pa_comm_info (C-ABI transport) / the process group
+        assert dp["comm_info"] is not None and dp["comm_info"]["nranks"] == world and dp["comm_info"]["rank"] == 0, dp["comm_info"]
+        if transport == "rccl_abi":
+            assert "rccl_version" in dp["comm_info"] and "C ABI" in dp["comm_info"]["backend"]
         _check_against_single_process(dp, ref, wire)
 
 
@@ -191,3 +195,23 @@ def test_bench_multi_rank_dry_run():
     ar = d["allreduce_measured"]
     assert len(ar["buckets"]) == 14 and ar["bytes_per_step"] > 300e6          # head + 12 blocks + patch embedding, f32
     assert all(b["in_flight_ms"] > 0 and b["exposed_wait_ms"] >= 0 for b in ar["buckets"])
+
+
+def test_bench_sweep_dry_run():
+    """`python bench.py --sweep-gpus 1,2` -- the single command that yields the weak-scaling curve on a multi-GPU node -- on the one
+    GPU of a test box: N = 1 for real, N = 2 as two self-launched ranks on device 0 over gloo (PASST_AMD_BENCH_DRY_GLOO=1).  One
+    JSON line per N, in order; the N = 2 line leads with the idle all-reduce figure and carries the communicator evidence; the
+    scaling model says which bus efficiency it used (the dry run must NOT feed its gloo figure into it)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PASST_AMD_BENCH_DRY_GLOO="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep-gpus", "1,2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert [d["n_gpus"] for d in lines] == [1, 2] and all(d["value"] > 0 for d in lines)
+    one, two = lines
+    assert one["config"]["global_batch"] == 4 and two["config"]["global_batch"] == 8 and "roofline" in one
+    assert two["rccl_nranks"] == 2 and two["allreduce_bus_GBps_idle"] == two["allreduce_measured"]["idle"]["bus_GBps_total"] > 0
+    assert list(two)[:16].index("allreduce_bus_GBps_idle") < list(two).index("config")
+    assert two["scaling_model"]["bus_efficiency"] == 0.35 and "ASSUMED" in two["scaling_model"]["inputs"]

@@ -426,6 +426,55 @@ def test_train_step_graph_equals_eager(loss, T):
         assert torch.equal(a, b)
 
 
+def test_train_step_graph_falls_back_to_eager_on_another_batch_shape():
+    """The reference's loaders never set drop_last: the last batch of an epoch is smaller.  TrainStep(graph=True) runs such a step
+    on the eager kernel sequence (decided before any random draw of the step) and keeps replaying its graph for the full batches
+    around it -- bit-identical to the eager TrainStep over the whole sequence; the loss it returns is a fresh tensor
+    per step (lazy collection); optimizer='sgd' with graph=True is refused at construction."""
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=951)
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    with pytest.raises(NotImplementedError, match="sgd"):
+        TrainStep(build(case, "bf16").train(), None, optimizer="sgd", graph=True)
+    sizes = [3, 3, 3, 3, 3, 2, 3, 1, 3]              # steps 0-2 eager warm-up, 3 captures, 5 and 7 are short batches
+    outs = []
+    for graph in (False, True):
+        net = build(case, "bf16").train()
+        ts = TrainStep(net, None, lr=1e-3, weight_decay=1e-2, use_mixup=True, graph=graph)
+        losses = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step, b in enumerate(sizes):
+                torch.manual_seed(80 + step)
+                np.random.seed(80 + step)
+                losses.append(ts.step(xg[:b], yg[:b]))              # kept lazily, read after the loop
+        torch.cuda.synchronize()
+        assert ts.t == len(sizes) and (not graph or "graph" in ts._g)
+        assert len({l.data_ptr() for l in losses}) == len(losses)
+        outs.append((torch.cat([l.reshape(1) for l in losses]).cpu(), ts.flat_p.clone(), ts.m.clone(), ts.v.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert len(set(outs[0][0].tolist())) == len(sizes)              # nine different losses: no aliasing of the captured tensor
+
+
+def test_my_mixup_results_are_on_the_device():
+    """passt_amd.mixup.my_mixup: the reference's draws (pinned on CPU, tests/test_caller_flow_cpu.py), uploaded: lam.to(device) is
+    a no-op and x[rn_indices] indexes with a device tensor -- no synchronising copy left in the caller's step."""
+    from passt_amd.mixup import my_mixup
+    torch.manual_seed(5)
+    np.random.seed(5)
+    i_cpu, l_cpu = my_mixup(64, 0.3, device="cpu")
+    torch.manual_seed(5)
+    np.random.seed(5)
+    i_dev, l_dev = my_mixup(64, 0.3)
+    assert i_dev.is_cuda and l_dev.is_cuda and i_dev.dtype == torch.int64 and l_dev.dtype == torch.float32
+    assert l_dev.to(l_dev.device) is l_dev
+    assert torch.equal(i_dev.cpu(), i_cpu) and torch.equal(l_dev.cpu(), l_cpu)
+    x = torch.randn(64, 1, 8, 8, device=DEV)
+    assert torch.equal(x[i_dev], x[i_cpu.to(DEV)])
+
+
 def test_optim_adamw_matches_torch():
     """passt_amd.optim.AdamW (one fused pa_adamw launch over the flat gradient buffer the autograd node returns) against
     torch.optim.AdamW on an identical twin, three steps of the real drop-in path with an LR scheduler; head_dist.* (never a
@@ -603,6 +652,48 @@ def test_config2_batch64_vs_reference_golden(golden_dir, name, precision):
     ts.close()
     record(f"{name}[{precision}]", logits=e_l, features=e_f, worst_grad_autograd=w_a, worst_grad_norm_autograd=wn_a,
            worst_grad_trainstep=w_t, worst_grad_norm_trainstep=wn_t)
+
+
+def test_model_speed_test_flow():
+    """The reference's own caller flow (ex_audioset.py:121-135 and model_speed_test :364-426) on the drop-in module:
+    ``torch.compile(net)``, ``torch.cuda.amp.autocast()`` (fp16), ``GradScaler``, ``SGD(net.parameters(), lr=1e-3)``,
+    x = ones(B,1,128,998), target = ones(B,527), at the reference's default batch of 12.  Checked: the compiled module's
+    logits are bit-identical to the eager module's under bf16 autocast (the compiler sees ONE opaque call, fp16 autocast selects
+    the same bf16 MFMA path) and within the bf16 bound of the exact-f32 mode; f32 logits; finite losses; the loss scale stays at
+    its initial 65536 (no inf / nan ever reaches the scaler); nothing is captured or recompiled; SGD moved the parameters."""
+    import copy
+    import bench
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(7)
+        net = passt_amd.get_model(arch="passt_s_swa_p16_128_ap476", pretrained=False, s_patchout_t=40, s_patchout_f=4).to(DEV).train()
+        twin = copy.deepcopy(net)
+        x = torch.ones(12, 1, 128, 998, device=DEV)
+        torch.manual_seed(99)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            eager_logits, eager_feat = twin(x)
+        twin.precision = "fp32"
+        torch.manual_seed(99)
+        with torch.no_grad():
+            f32_logits, _ = twin(x)
+        compiled = torch.compile(net)
+        torch.manual_seed(99)
+        with torch.cuda.amp.autocast():
+            logits, feat = compiled(x)
+        assert logits.dtype == torch.float32 and feat.dtype == torch.float32 and logits.requires_grad
+        assert torch.equal(logits.detach(), eager_logits) and torch.equal(feat.detach(), eager_feat)
+        e = rel(logits.detach().cpu(), f32_logits.cpu())
+        assert e < BF16_LOGITS, e
+        del logits, feat
+        before = net.head[1].bias.detach().clone()
+        r = bench.speed_test_flow(net, 12, warmup=3, test_length=6)
+    assert np.isfinite(r["first_loss"]) and np.isfinite(r["last_loss"]) and 0.0 < r["last_loss"] < 5.0
+    assert r["grad_scale"] == 65536.0, r                     # GradScaler's initial scale: never backed off
+    assert r["logits_dtype"] == "torch.float32"
+    assert r["dynamo"]["graphs_captured"] == 0 and r["dynamo"]["frames_total"] == r["dynamo"]["frames_after_warmup"] <= 1, r
+    assert not torch.equal(before, net.head[1].bias.detach())
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    record("speed_test_flow[B=12]", compiled_vs_f32_logits=e, specs_per_second=r["specs_per_second"])
 
 
 def test_ensemble_and_other_strides_eval():

@@ -88,3 +88,32 @@ def test_versions_bump_and_state_dict_round_trip():
     got, _ = _run(_RefLaunch, True, steps=5, reload_at=3)
     for a, b in zip(got, ref):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+def test_step_count_is_per_parameter_like_torch():
+    """A parameter whose first gradient arrives later (unfrozen layer) gets the bias correction of ITS first step, not of the
+    group's step count: torch.optim.AdamW keeps state[p]['step'] per parameter.  Also across a state_dict round
+    trip with heterogeneous steps."""
+    def run(opt_cls, reload_at=None):
+        ps = _params(5)
+        opt = opt_cls(ps, lr=1e-2, weight_decay=0.05)
+        for s in range(8):
+            if reload_at == s:
+                sd = copy.deepcopy(opt.state_dict())
+                opt = opt_cls(ps, lr=1e-2, weight_decay=0.05)
+                opt.load_state_dict(sd)
+            _set_grads(ps, s, True)
+            if s < 5:                                   # parameters 2 and 5 are "frozen" for the first five steps
+                ps[2].grad = None
+                ps[5].grad = None
+            opt.step()
+            opt.zero_grad()
+        return ps, opt
+    ref, ropt = run(torch.optim.AdamW)
+    for reload_at in (None, 6):
+        got, opt = run(_RefLaunch, reload_at)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), i
+        for p, q in zip(got[:-1], ref[:-1]):
+            assert float(opt.state[p]["step"]) == float(ropt.state[q]["step"])
+        assert float(opt.state[got[2]]["step"]) == 3.0 and float(opt.state[got[0]]["step"]) == 8.0
