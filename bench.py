@@ -325,6 +325,9 @@ def speed_test_flow(net, batch_size, warmup=10, test_length=100, compile_net=Tru
             loss, y_hat = one()
         torch.cuda.synchronize()
         t_warm = time.time() - t1
+        import gc
+        gc.collect()
+        gc.freeze()             # torch.compile imported ~900 modules: keep full collections of them out of the timed loop
         frames_after_warmup = counters["frames"].get("total", 0)
         first_loss = float(loss.item())
         t1 = time.time()
@@ -623,6 +626,11 @@ def run(args):
         for _ in range(args.warmup):
             ts.step(x, y)
         barrier()
+        # the per-launch HIP events of the instrumented steps are thousands of small Python objects: keep the cyclic collector
+        # from walking everything the process has imported while the clock runs (objects alive now become permanent)
+        import gc
+        gc.collect()
+        gc.freeze()
         if getattr(ts, "phases", None) is not None:
             ts.phases.clear()                   # phase diagnostics: timed steps only (warm-up carries one-time module loads)
         # per-launch HIP events on the GEMM family (roofline): two event records per launch cost ~3.4 % of the step

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 4   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
-                            * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info, pa_adamw_dev / pa_adamw_hyper, PA_GEMM_EPILOGUE_V3 */
+#define PA_ABI_VERSION 5   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
+                            * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info, pa_adamw_dev / pa_adamw_hyper, PA_GEMM_EPILOGUE_V3;
+                            * 5 (round 5): PA_ATTN_BWD_TWO_PASS (pa_attention_bwd defaults to the single-pass kernel where it applies) */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -274,6 +275,13 @@ int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumul
  * (dqkv's q third is the gradient with respect to the UNSCALED q).  The same flag must be given to fwd and bwd.
  * ------------------------------------------------------------------------------------------ */
 #define PA_ATTN_Q_PRESCALED 1
+/* pa_attention_bwd only (ABI 5).  bf16 + PA_ATTN_Q_PRESCALED + nq == N <= 512 can run as ONE kernel (one workgroup per
+ * (sequence, head): S / dP / exp formed once, dQ contracted over all keys through an LDS transposition buffer; `delta` is then not
+ * touched) instead of the dQ kernel followed by the dK/dV kernel: same quantities, both deterministic.  By default the library
+ * picks the single pass when B * H >= 512 (two rounds of 256 CUs).  PA_ATTN_BWD_TWO_PASS forces the kernel pair,
+ * PA_ATTN_BWD_SINGLE_PASS the single kernel wherever it applies (elsewhere it is ignored). */
+#define PA_ATTN_BWD_TWO_PASS 2
+#define PA_ATTN_BWD_SINGLE_PASS 4
 int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                      float scale, int dtype, int flags, void* stream);
 /* number of floats of pa_attention_bwd's `delta` workspace */

@@ -126,7 +126,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype, fn.argtypes = res, args
-    if lib.pa_abi_version() != 4:      # include/passt_amd.h PA_ABI_VERSION
+    if lib.pa_abi_version() != 5:      # include/passt_amd.h PA_ABI_VERSION
         raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

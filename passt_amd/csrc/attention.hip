@@ -280,9 +280,21 @@ template <typename F> __device__ __forceinline__ F lds_b128_asm(const char* lds_
     asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_ptr));
     return __builtin_bit_cast(F, r);
 }
+// the same with an immediate offset (must fold to a constant after inlining / unrolling)
+template <typename F> __device__ __forceinline__ F lds_b128_imm(uint32_t lds_addr, int off) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(off));
+    return __builtin_bit_cast(F, r);
+}
 // pending must fold to a constant after inlining / unrolling
 template <typename F> __device__ __forceinline__ void frag_settle(F& a, F& b, int pending) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(pending));
+}
+// one fragment (never pass the SAME variable twice to frag_settle: two tied operands of one asm get a register copy of the
+// in-flight value in front of the wait)
+template <typename F> __device__ __forceinline__ void frag_settle1(F& a, int pending) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(pending));
 }
 __device__ __forceinline__ void wave_static_prio() {
 #if PA_ATTN_PRIO == 1
@@ -829,6 +841,364 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, SINGLE PASS (round 5): bf16, q pre-scaled, nq == N <= 512.  One 512-thread workgroup per (sequence, head).
+//
+// The two-kernel backward above issues 7 tile products for the 5 the algorithm has (S and dP are formed once with lane =
+// query for dQ and once with lane = key for dK / dV) and evaluates P = exp2(S - lse) twice.  Here every 32 x 32 block of
+// (S, dP) is formed ONCE, in the orientation dK / dV need (lane = key): wave w owns keys [64 w, 64 w + 64) for the whole
+// kernel, its dK / dV accumulators (128 registers) and V row fragments (32) stay in registers, the K rows of the head
+// stay in LDS (they feed the score product as row fragments and the dQ product as column fragments), and Q / dO stream
+// through LDS in double-buffered tiles of 32 queries.  dQ needs dS with lane = query -- the other orientation -- and a
+// sum over ALL keys, i.e. over all waves.  Both are solved through LDS at once: every wave drops its bf16 dS block into
+// the transposition buffer T[key][query] (4 ds_write_b64 per block; it rounds dS to bf16 for the dK product anyway), and
+// after ONE barrier per query tile ("phase 2") each wave owns one 16 x 16 tile of dQ^T[64 d][32 q] and contracts it over
+// all keys with v_mfma_f32_16x16x32_bf16, both operands fetched by transposed LDS reads (K^T from the resident K rows,
+// dS^T from T): no cross-wave reduction of partial sums, no atomics, deterministic.  T is double buffered, so phase 2 of
+// tile t overlaps phase 1 of tile t + 1 on the other wave of the SIMD.
+// Per (64 keys x 32 queries): 32 + 4 (x 0.5) MFMAs of 32x32x16 worth of matrix work instead of 56, one exp pass instead
+// of two, no delta hand-over launch; Q / dO / K / V are read from HBM once per head instead of 4 + 4 times.
+// LDS: K 64 KiB + T 2 x 32 KiB + Q/dO stages 2 x 8 KiB + per-query scalars 4 KiB = 148 KiB (one workgroup per CU, two
+// waves per SIMD, 256 registers each).  Index math of T and of the phase-2 operand fetches: tools/emulate_attn_bwd_fused.py
+// (values and bank conflicts under the MI355X lane-group rules, on the CPU).
+// ------------------------------------------------------------------------------------------------
+// timing ablations (A/B builds only, results are wrong): 1 = no phase 2, 2 = no exp / dS arithmetic, 4 = no dV / dK products (and no
+// column fragments, no T writes), 8 = no score products, 16 = no barrier per tile
+#ifndef PA_FUSED_ABL
+#define PA_FUSED_ABL 0
+#endif
+#ifndef PA_FUSED_INTERLEAVE
+#define PA_FUSED_INTERLEAVE 0
+#endif
+static constexpr int FK = 512;                                   // key rows of the resident K tile (N <= FK)
+static constexpr int FT_PLANE = FK * 32;                         // one 16-query plane of T: FK keys x 16 queries x 2 B
+static constexpr int F_OFF_T = FK * 128;
+static constexpr int F_STAGE = 2 * 32 * 128;                     // Q tile + dO tile, 32 rows each
+static constexpr int F_OFF_STAGE = F_OFF_T + 2 * 2 * FT_PLANE;
+static constexpr int F_OFF_LSE = F_OFF_STAGE + 2 * F_STAGE;
+static constexpr int F_OFF_DELTA = F_OFF_LSE + FK * 4;
+static constexpr int F_LDS = F_OFF_DELTA + FK * 4;               // 151 552 B
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// column fragment (see col_frag) from two absolute per-lane LDS addresses and an immediate: issued only, settle with col_settle<>()
+__device__ __forceinline__ bf16x8 tr_frag(uint32_t a0, uint32_t a1, int imm) {
+    const bf16x4 lw = lds_tr16_asm_imm(a0, imm), hi = lds_tr16_asm_imm(a1, imm);
+    bf16x8 f;
+    f[0] = lw[0]; f[1] = lw[1]; f[2] = lw[2]; f[3] = lw[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_kernel(
+    const bf16* __restrict__ qkv, int ldqkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int ldo,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    using T = bf16;
+    using F = bf16x8;
+    constexpr int NF = 4, NS = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh % H;
+    const int D = H * HD;
+    const T* base = qkv + (int64_t)b * N * ldqkv + h * HD;       // q of token 0 of this (b, h)
+    const T* dobase = d_o + (int64_t)b * N * ldo + h * HD;
+    const T* obase = o + (int64_t)b * N * ldo + h * HD;
+    const int ldbq = ldqkv * 2, ldbo = ldo * 2;
+    char* sK = smem;
+    char* sT = smem + F_OFF_T;
+    char* sStage = smem + F_OFF_STAGE;
+    float* sLse = (float*)(smem + F_OFF_LSE);
+    float* sDelta = (float*)(smem + F_OFF_DELTA);
+    const int hf = lane >> 5, l31 = lane & 31;
+    const int nt = (N + 31) >> 5;                                // query tiles == key steps of phase 2
+    constexpr int nk4 = FK / 32;                                 // phase 2 always walks all FK key rows (16 steps): rows up to there must be finite
+
+    // ---- prologue.  K rows -> sK and V rows -> the T region (8 rows per 1 KiB request, all FK rows, rows >= N as copies of row
+    // N - 1): the V rows are only there to be picked up as this wave's row fragments (coalesced LDS-DMA + ds_read_b128 instead of a
+    // lane-per-row walk through global memory), and they leave every byte of T FINITE -- phase 2 reads T rows no wave ever writes
+    // (keys in [32 nt, FK)) and multiplies them by the zero rows behind key N - 1 of the K tile
+    {
+        const char* gK = (const char*)(base + D);
+        const char* gV = (const char*)(base + 2 * D);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rq = wave * 8 + i;
+            const int row = rq * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_f128(row);
+            const int64_t goff = (int64_t)min(row, N - 1) * ldbq + c * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gK + goff),
+                                             (__attribute__((address_space(3))) void*)(sK + rq * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gV + goff),
+                                             (__attribute__((address_space(3))) void*)(sT + rq * 1024), 16, 0, 0);
+        }
+    }
+    // Q / dO tile t -> stage buffer: 8 requests of 8 rows, one per wave (waves 0-3: Q, 4-7: dO)
+    const int st_tensor = wave >> 2, st_piece = wave & 3;
+    const int st_row = st_piece * 8 + (lane >> 3);
+    const int st_chunk = ((lane & 7) ^ swz_f128(st_row)) * 16;
+    const char* st_src = st_tensor ? (const char*)dobase : (const char*)base;
+    const int st_ldb = st_tensor ? ldbo : ldbq;
+    auto stage = [&](int t) __attribute__((always_inline)) {
+        const int grow = min(t * 32 + st_row, N - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st_src + (int64_t)grow * st_ldb + st_chunk),
+                                         (__attribute__((address_space(3))) void*)(sStage + (t & 1) * F_STAGE + st_tensor * 4096 + st_piece * 1024), 16, 0, 0);
+    };
+    stage(0);
+    const int kbase0 = wave * 64;
+    F vf[2][NF];                                                 // filled after the first barrier
+    // per-query scalars in the form the score chains take as C operand: -lse * log2(e), -delta = -rowsum(dO * O).  Wave w owns
+    // queries [64 w, 64 w + 64): eight lanes per row, 16 bytes each (full 128-byte lines: a lane-per-row walk of the same rows costs
+    // the texture path 8 x as many line requests -- the prologue is not overlapped with anything, one workgroup per CU)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = wave * 64 + i * 8 + (lane >> 3);
+        if (wave * 64 + i * 8 < nt * 32) {                       // wave-uniform
+            const int qrow = min(q, N - 1);
+            const int off = (lane & 7) * 8;
+            const F df = *(const F*)(dobase + (int64_t)qrow * ldo + off);
+            const F of = *(const F*)(obase + (int64_t)qrow * ldo + off);
+            float dlt = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dlt = fmaf((float)df[e], (float)of[e], dlt);
+            dlt += __shfl_xor(dlt, 1);
+            dlt += __shfl_xor(dlt, 2);
+            dlt += __shfl_xor(dlt, 4);
+            // queries past N (last tile; their Q / dO rows are copies of row N - 1): C operand -inf, so P = exp2(-inf) = 0 and
+            // dS = P * finite = 0 -- they contribute nothing to dK / dV and no tile needs a mask
+            if ((lane & 7) == 0) {
+                sDelta[q] = -dlt;
+                sLse[q] = q < N ? -lse[(int64_t)bh * N + qrow] * LOG2E : -INFINITY;
+            }
+        }
+    }
+    // ---- per-lane ABSOLUTE LDS addresses, set up once: every access of the tile loop is one of these registers plus an
+    // immediate (the stage / T buffer of a tile is a compile-time constant: the tile loop is unrolled by two)
+    typedef __attribute__((address_space(3))) char lchar;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lchar*)smem;
+    LaneOff<T> lo;
+    lane_offsets<T>(lo, lane);
+    uint32_t aS[NF], aC[2][2];
+#pragma unroll
+    for (int st = 0; st < NF; ++st) aS[st] = lds0 + F_OFF_STAGE + lo.rowf[st];    // row fragment st of stage row (lane & 31): Q (+ BUF * F_STAGE), dO (+ 4096)
+    // the same fragment of this wave's K row (key block 1: + 4096) is aS[st] + kdelta: four v_add per block instead of four registers
+    const int kdelta = kbase0 * 128 - F_OFF_STAGE;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { aC[db][0] = lds0 + F_OFF_STAGE + lo.colf[db][0]; aC[db][1] = lds0 + F_OFF_STAGE + lo.colf[db][1]; }
+    // T writes of phase 1: row = key, 8-byte slot (4 queries) h + 2 e, XOR-swizzled by key bits 2..3 (key block 1 = + 32 keys =
+    // + 1024 bytes, same swizzle; the second slot is the first ^ 2: byte offset ^ 16, T is 32-byte aligned inside the 1 KiB-aligned
+    // dynamic LDS).  Lanes whose key is past N write their (finite) dS column like everybody else: phase 2 multiplies it by the
+    // ZERO rows the prologue put behind key N - 1 of the K tile.
+    const uint32_t aT0 = lds0 + (uint32_t)(F_OFF_T + (kbase0 + l31) * 32 + ((hf ^ (((kbase0 + l31) >> 2) & 3)) << 3));
+    // phase 2: this wave's tile of dQ^T is (d16, q16); lane = (g4, p): piece row r = p >> 2, column group cg = p & 3
+    const int d16 = wave & 3, q16 = wave >> 2;
+    auto ld128 = [](uint32_t addr) { return *(const __attribute__((address_space(3))) F*)(size_t)addr; };
+    auto ld4f = [](uint32_t addr) { return *(const __attribute__((address_space(3))) f32x4*)(size_t)addr; };
+    auto st64 = [](uint32_t addr, uint32_t w0, uint32_t w1) { *(__attribute__((address_space(3))) u32x2_t*)(size_t)addr = u32x2_t{w0, w1}; };
+    f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { dk[kb][db] = acc_splat(0.f); dv[kb][db] = acc_splat(0.f); }
+
+    // one block: 32 queries of tile t (stage / T buffer BUF) against key block kb of this wave
+    auto block = [&](auto kb_tag, auto buf_tag, int t) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kb_tag)::value, BUF = decltype(buf_tag)::value;
+        constexpr int OQ = BUF * F_STAGE, ODO = OQ + 4096;
+        f32x16 sa, dpa;
+        // per-query scalars of accumulator rows 8 g + 4 h + {0..3}: + g * 32 (recomputed per block: the kernel has no register to spare)
+        uint32_t hsel = (uint32_t)lane;
+        asm volatile("" : "+v"(hsel));
+        const uint32_t sc = lds0 + F_OFF_LSE + ((hsel >> 5) << 4) + (uint32_t)t * 128u;
+        // S'[q][key] = (Q sl2) K^T - lse      (A rows = q, B cols = key = lane); C operand = -lse * log2(e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = ld4f(sc + g * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sa[4 * g + e] = a[e];
+        }
+        // the fragment reads are asm (issued where they are written, settled by counted waits): left to itself the compiler, at
+        // the register limit, either hoists all twelve loads and spills the V fragments or serialises load -> wait -> MFMA
+        if (!(PA_FUSED_ABL & 8)) {
+            F qf[NF], kf[NF];
+#pragma unroll
+            for (int st = 0; st < NF; ++st) {
+                qf[st] = lds_b128_imm<F>(aS[st], OQ);
+                kf[st] = lds_b128_imm<F>(aS[st] + (uint32_t)kdelta, kb * 4096);
+            }
+#pragma unroll
+            for (int st = 0; st < NF; ++st) {
+                frag_settle(qf[st], kf[st], 2 * (NF - 1 - st));
+                mma32<T>(sa, qf[st], kf[st]);
+            }
+        }
+        // dP'[q][key] = dO V^T - delta: requested behind the score chain, whose MFMAs cover the latency
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 d = ld4f(sc + FK * 4 + g * 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dpa[4 * g + e] = d[e];
+        }
+        // (column fragments single-buffered: 16 registers, not 32 -- the kernel sits at the 256-register limit of two waves per
+        // SIMD, and a spilled accumulator inside the tile loop drains the Q / dO prefetch in front of its reload.  The first
+        // set is requested in front of the dP chain / the exponentials, which cover its latency)
+        F cf[4];
+        auto issue_cf = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                cf[db] = tr_frag(aC[db][0], aC[db][1], ODO + 16 * st * 128);
+                cf[2 + db] = tr_frag(aC[db][0], aC[db][1], OQ + 16 * st * 128);
+            }
+        };
+        if (!(PA_FUSED_ABL & 8)) {
+            F df[NF];
+#pragma unroll
+            for (int st = 0; st < NF; ++st) df[st] = lds_b128_imm<F>(aS[st], ODO);
+            if (!(PA_FUSED_ABL & 4)) issue_cf(0);
+#pragma unroll
+            for (int st = 0; st < NF; ++st) {
+                frag_settle1(df[st], NF - 1 - st + ((PA_FUSED_ABL & 4) ? 0 : 8));
+                mma32<T>(dpa, df[st], vf[kb][st]);
+#if PA_FUSED_INTERLEAVE
+                // the exponentials of four score rows behind each MFMA of the dP chain (in ONE wave VALU work issued behind an
+                // MFMA runs in its shadow; across waves it does not: profiles/r04_mfma_valu_arbitration.txt)
+                if (!(PA_FUSED_ABL & 2)) {
+#pragma unroll
+                    for (int r = 4 * st; r < 4 * st + 4; ++r) sa[r] = __builtin_amdgcn_exp2f(sa[r]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                }
+#endif
+            }
+        } else if (!(PA_FUSED_ABL & 4)) {
+            issue_cf(0);
+        }
+        if (!(PA_FUSED_ABL & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#if !PA_FUSED_INTERLEAVE
+                sa[r] = __builtin_amdgcn_exp2f(sa[r]);
+#endif
+                dpa[r] *= sa[r];                                // dS / scale
+            }
+        }
+        if (PA_FUSED_ABL & 4) {
+            asm volatile("" :: "v"(sa), "v"(dpa));
+            return;
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key] ; T[key][q] = bf16(dS)
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st > 0) issue_cf(st);
+            const F pf = acc_frag<T>(sa, st), dsf = acc_frag<T>(dpa, st);
+            col_settle<0>(cf[0], cf[1], cf[2], cf[3]);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mma32<T>(dv[kb][db], cf[db], pf);
+                mma32<T>(dk[kb][db], cf[2 + db], dsf);
+            }
+            // queries 16 st + 4 h + {0..3} (slot h) and + 8 (slot h + 2 = slot ^ 2 after the key swizzle: byte offset ^ 16)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = __builtin_bit_cast(u32x4, dsf);
+            const int TOFF = BUF * (2 * FT_PLANE) + st * FT_PLANE + kb * 1024;
+            st64(aT0 + TOFF, w[0], w[1]);
+            st64((aT0 ^ 16u) + TOFF, w[2], w[3]);
+        }
+    };
+    // phase 2 of tile t: dQ^T tile (d16, q16) = sum over keys, 4 NCH steps of 32 keys.  Straight-line: the transposed reads are
+    // asm the compiler cannot see, so nothing in flight may cross a control-flow merge; the four reads of step k + 3 are issued
+    // in front of the MFMA of step k and settled in issue order.  Steps past the last key multiply finite T rows
+    // (zeros from the prologue, or dS columns of lanes past N) by the zero rows behind key N - 1 of the K tile.
+    auto phase2 = [&](auto buf_tag, auto nch_tag, int t) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value, NCH = decltype(nch_tag)::value;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the two per-lane base addresses are recomputed per tile (a dozen VALU) instead of living in registers across phase 1
+        uint32_t p2K, p2T;
+        {
+            uint32_t ln = (uint32_t)lane;
+            asm volatile("" : "+v"(ln));
+            const int g4 = ln >> 4, p = ln & 15, r = p >> 2, cg = p & 3;
+            const int kl = 4 * g4 + r;                           // key inside a 32-key step: kl (first read), 16 + kl (second)
+            const int d = d16 * 16 + cg * 4;
+            p2K = lds0 + (uint32_t)(swz128(kl, d >> 3) + (d & 7) * 2);
+            p2T = lds0 + (uint32_t)(F_OFF_T + q16 * FT_PLANE + kl * 32 + ((cg ^ g4) << 3));
+        }
+        constexpr int NSTEP = 4 * NCH, AHEAD = 3;               // lgkmcnt counts to 15: three steps (12 reads) in flight
+        bf16x4 ka[4][2], ta[4][2];                              // ring of four steps
+        auto issue = [&](int k) {
+            ka[k & 3][0] = lds_tr16_asm_imm(p2K, k * 4096);
+            ka[k & 3][1] = lds_tr16_asm_imm(p2K, k * 4096 + 2048);
+            ta[k & 3][0] = lds_tr16_asm_imm(p2T, BUF * (2 * FT_PLANE) + k * 1024);
+            ta[k & 3][1] = lds_tr16_asm_imm(p2T, BUF * (2 * FT_PLANE) + k * 1024 + 512);
+        };
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) issue(k);
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            if (k + AHEAD < NSTEP) issue(k + AHEAD);
+            bf16x4 &k0 = ka[k & 3][0], &k1 = ka[k & 3][1], &t0 = ta[k & 3][0], &t1 = ta[k & 3][1];
+            const int younger = (NSTEP - 1 - k) < AHEAD ? (NSTEP - 1 - k) : AHEAD;      // steps issued after this one
+            if (younger == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k0), "+v"(k1), "+v"(t0), "+v"(t1) : "n"(PA_ATTN_DEBUG_WAIT ? 0 : 12));
+            else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k0), "+v"(k1), "+v"(t0), "+v"(t1) : "n"(PA_ATTN_DEBUG_WAIT ? 0 : 8));
+            else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k0), "+v"(k1), "+v"(t0), "+v"(t1) : "n"(PA_ATTN_DEBUG_WAIT ? 0 : 4));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0), "+v"(k1), "+v"(t0), "+v"(t1));
+            const F a = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+            const F bq = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, acc, 0, 0, 0);
+        }
+        // lane holds dQ^T[d = 16 d16 + 4 g4 + {0..3}][q = 16 q16 + p]: 8 bytes of row q; gradient w.r.t. the TRUE q
+        const int q = t * 32 + q16 * 16 + (lane & 15);
+        if (q < N) {
+            const bf16x2 lo2 = {(bf16)(acc[0] * scale), (bf16)(acc[1] * scale)}, hi2 = {(bf16)(acc[2] * scale), (bf16)(acc[3] * scale)};
+            *(u32x2_t*)(dqkv + ((int64_t)b * N + q) * lddqkv + h * HD + d16 * 16 + 4 * (lane >> 4)) =
+                u32x2_t{__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2)};
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // V row fragments of this wave's keys (B operand of the dP products), from the V rows parked in the T region
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < NF; ++st) vf[kb][st] = ld128(lds0 + F_OFF_T + (kbase0 + kb * 32) * 128 + lo.rowf[st]);
+    // K rows behind the last key := 0 (so that the dS columns of lanes past N, and the T rows nobody writes, contribute nothing
+    // to dQ); the scores of those lanes become exp2(-lse): finite
+    for (int i = tid; i < (nk4 * 32 - N) * 8; i += 512) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        *(u32x4*)(sK + (N + (i >> 3)) * 128 + (i & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    auto tile = [&](auto buf_tag, int t) __attribute__((always_inline)) {
+        if (t + 1 < nt) stage(t + 1);
+        if (kbase0 < N) block(std::integral_constant<int, 0>{}, buf_tag, t);
+        if (kbase0 + 32 < N) block(std::integral_constant<int, 1>{}, buf_tag, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(PA_FUSED_ABL & 16)) __syncthreads();
+        // phase 2 walks the whole K tile (16 steps of 32 keys) whatever N is: straight-line code, one instantiation; at the
+        // headline 474 tokens that is one step more than the 15 that hold keys
+        if (!(PA_FUSED_ABL & 1)) phase2(buf_tag, std::integral_constant<int, 4>{}, t);
+    };
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nt) tile(std::integral_constant<int, 0>{}, t);
+    T* out = dqkv + (int64_t)b * N * lddqkv + h * HD;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                                 // the row pointers are formed here, not kept in registers across the tile loop
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int k0 = kbase0 + kb * 32;
+        if (k0 < N) {
+            // the Q rows in memory are Q * scale * log2(e): dK = dS^T Q * scale = acc * ln 2
+            store_rows_direct<T>(dk[kb], LN2, out + D, lddqkv, k0, min(32, N - k0), ln);
+            store_rows_direct<T>(dv[kb], 1.0f, out + 2 * D, lddqkv, k0, min(32, N - k0), ln);
+        }
+    }
+}
+
 template <typename T> static size_t fwd_lds() { return 4 * Tile<T>::BYTES; }   // K/V double buffer
 template <typename T> static size_t dkdv_lds() { return 2 * (2 * Tile<T>::BYTES + 2 * TROWS * 4); }
 
@@ -883,10 +1253,22 @@ extern "C" int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, fl
 extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const void* d_o, int ldo,
                                 const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
                                 float scale, int dtype, int flags, void* stream) {
-    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N || (flags & ~PA_ATTN_Q_PRESCALED)) return PA_EINVAL;
+    if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N ||
+        (flags & ~(PA_ATTN_Q_PRESCALED | PA_ATTN_BWD_TWO_PASS | PA_ATTN_BWD_SINGLE_PASS)))
+        return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype) || !attn_args_ok(lddqkv, dtype)) return PA_EUNSUPPORTED;
     const bool pre = flags & PA_ATTN_Q_PRESCALED;
     hipStream_t st = (hipStream_t)stream;
+    // single pass where it applies and fills the chip: one workgroup per (sequence, head) takes a whole CU (148 KiB of LDS), so B * H
+    // below two rounds of 256 CUs leaves the two-kernel form (3-4 x as many, smaller workgroups) ahead -- ESC-50 at batch 12: 144
+    const bool can_fuse = dtype == PA_BF16 && pre && nq == N && N <= FK;
+    if (can_fuse && !(flags & PA_ATTN_BWD_TWO_PASS) && ((flags & PA_ATTN_BWD_SINGLE_PASS) || (int64_t)B * H >= 512)) {
+        static const int attr_rc = (int)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (attr_rc) return PA_ELAUNCH;
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(B * H)), dim3(512), F_LDS, st, (const bf16*)qkv, ldqkv, (const bf16*)o,
+                           (const bf16*)d_o, ldo, lse, (bf16*)dqkv, lddqkv, H, N, scale);
+        return check_launch();
+    }
     if (dtype == PA_BF16)
         return pre ? attention_bwd_t<bf16, true>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st)
                    : attention_bwd_t<bf16, false>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st);

@@ -589,6 +589,9 @@ def colsum_f32(x, out_f32, accumulate=False):
 
 # ---- attention -------------------------------------------------------------------------------
 ATTN_Q_PRESCALED = 1          # include/passt_amd.h PA_ATTN_Q_PRESCALED
+ATTN_BWD_TWO_PASS = 2         # PA_ATTN_BWD_TWO_PASS: force the dQ + dK/dV kernel pair (A/B, tests); PASST_AMD_ATTN_BWD=two_pass sets it everywhere
+ATTN_BWD_SINGLE_PASS = 4      # PA_ATTN_BWD_SINGLE_PASS: force the single-pass kernel wherever it applies; PASST_AMD_ATTN_BWD=single_pass
+_ATTN_BWD_FORCE = {"two_pass": ATTN_BWD_TWO_PASS, "single_pass": ATTN_BWD_SINGLE_PASS}.get(os.environ.get("PASST_AMD_ATTN_BWD", ""), 0)
 LOG2E = 1.4426950408889634
 
 
@@ -619,7 +622,7 @@ def attention_bwd(qkv, o, d_o, lse, B, H, N, scale, nq=None, flags=0):
     _timed("attn_bwd", 10.0 * nq * N * 64 * B * H,      # five N x N x 64 products: S, dP, dV, dK, dQ
            lambda: check(lib.pa_attention_bwd(_p(qkv, None, True), qkv.stride(0), _p(o, qkv.dtype, True), _p(d_o, qkv.dtype, True),
                                               o.stride(0), _p(lse, torch.float32), _p(delta), _p(dqkv), dqkv.stride(0), B, H, N, nq,
-                                              scale, dtype, flags, _stream()), "pa_attention_bwd"))
+                                              scale, dtype, flags | _ATTN_BWD_FORCE, _stream()), "pa_attention_bwd"))
     return dqkv
 
 

@@ -21,6 +21,7 @@ Patchout indices are drawn with the reference's own torch CPU RNG calls in the r
 """
 import math
 import os
+import sys
 import warnings
 from collections import OrderedDict
 from functools import partial
@@ -31,6 +32,25 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import EPI_DGELU, EPI_RESID, EPI_STORE, PA_BF16, PA_F32, PasstAmdError
+
+
+# torch.compile(net) must see the forward as ONE opaque call (see PaSST.forward): torch.compiler.disable.  Applied LAZILY, the first
+# time anything is registered on a module after torch._dynamo was imported (torch.compile(net) builds an OptimizedModule and assigns
+# net to it) or by net.compile(): decorating at import time would import torch._dynamo (~900 modules, millions of GC-tracked
+# objects) into every process that only wants the eager path -- measured on MI355X: with it loaded, Python's cyclic collector costs
+# bench.py's per-launch event bookkeeping +6 ms per step at ESC-50's batch 12 (profiles/r05_dynamo_import_gc.txt).
+_OPAQUE = {"done": False}
+
+
+def make_opaque_to_compile():
+    if _OPAQUE["done"]:
+        return
+    _OPAQUE["done"] = True
+    from . import preprocess
+    PaSST.forward = torch.compiler.disable(PaSST.forward)
+    cls = getattr(preprocess.AugmentMelSTFT, "__wrapped__", preprocess.AugmentMelSTFT)       # (a ba3l command wraps the class)
+    if isinstance(cls, type):
+        cls.forward = torch.compiler.disable(cls.forward)
 
 
 def to_2tuple(x):
@@ -541,6 +561,8 @@ _TREE_EPOCH = [0]
 
 def _bump_tree_epoch(*_a):
     _TREE_EPOCH[0] += 1
+    if not _OPAQUE["done"] and "torch._dynamo" in sys.modules:       # somebody is about to compile: see make_opaque_to_compile()
+        make_opaque_to_compile()
 
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_bump_tree_epoch)
@@ -683,12 +705,17 @@ class PaSST(nn.Module):
         """Call after updating parameters through raw device pointers (passt_amd.optim does)."""
         self._staged.epoch += 1
 
-    @torch.compiler.disable
+    def compile(self, *args, **kwargs):
+        """nn.Module.compile (in-place torch.compile of __call__): the forward stays one opaque eager call, see forward()."""
+        import torch._dynamo  # noqa: F401
+        make_opaque_to_compile()
+        return super().compile(*args, **kwargs)
+
     def forward(self, x):
         """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595).
 
         ``torch.compile(net)`` (ex_audioset.py:135, model_speed_test :391): the whole forward is ONE opaque call to the
-        compiler (``torch.compiler.disable``) -- there is nothing for Inductor to fuse, every kernel of the network is already
+        compiler (``torch.compiler.disable``, installed by make_opaque_to_compile() when a compile is set up) -- there is nothing for Inductor to fuse, every kernel of the network is already
         a hand-written launch behind the C ABI, and dynamo cannot trace ctypes calls; the compiled module therefore runs this
         function eagerly, captures no graph and never recompiles (tests/test_abi_cpu.py, tests/test_gpu_model.py speed-test
         flow).  Under ``torch.autocast`` of either 16-bit type (Lightning precision=16 / torch.cuda.amp.autocast() are fp16) the

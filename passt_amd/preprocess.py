@@ -85,8 +85,7 @@ class AugmentMelSTFT(nn.Module):
         self.register_buffer("_bin_mel", bin_mel.float(), persistent=False)
         self.register_buffer("_twiddle", tw.float().contiguous(), persistent=False)
 
-    @torch.compiler.disable          # one hand-written launch: opaque to torch.compile (the reference compiles only the net anyway)
-    def forward(self, x):
+    def forward(self, x):           # (opaque to torch.compile like PaSST.forward: passt.make_opaque_to_compile)
         if not x.is_cuda:
             raise PasstAmdError("passt_amd.AugmentMelSTFT runs on a HIP device only (no CPU fallback)")
         if x.dim() != 2:

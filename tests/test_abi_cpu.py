@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
         assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.pa_abi_version() == 4
+    assert lib.pa_abi_version() == 5
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
     assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768

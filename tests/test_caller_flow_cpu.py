@@ -6,6 +6,7 @@
   eager call -- no graph is captured, nothing is recompiled on later calls (the GPU half of this is
   tests/test_gpu_model.py::test_model_speed_test_flow).
 """
+import os
 import warnings
 
 import numpy as np
@@ -58,6 +59,23 @@ def test_count_non_zero_params_walks_the_module():
     desc, total, nonzero = count(net)
     assert total == sum(p.numel() for p in net.parameters()) == 86_153_758          # passt_s / 527 classes
     assert 0 < nonzero <= total and "type Linear, weight" in desc and "type PaSST, cls_token" in desc
+
+
+def test_eager_import_does_not_load_dynamo():
+    """The eager path must not import torch._dynamo (its ~900 modules make every full cyclic-GC pass of the process far more
+    expensive: measured +6 ms per training step at ESC-50's batch 12 with bench.py's event bookkeeping): the compiler-opaque
+    wrapper of PaSST.forward is installed only when a compile is being set up."""
+    import subprocess
+    import sys
+    code = ("import sys, warnings; warnings.simplefilter('ignore'); import passt_amd; "
+            "net = passt_amd.PaSST(img_size=(128, 250), stride=10, num_classes=7, embed_dim=128, depth=1, num_heads=2, distilled=True); "
+            "mel = passt_amd.AugmentMelSTFT(); "
+            "assert 'torch._dynamo' not in sys.modules and not passt_amd.passt._OPAQUE['done']; "
+            "import torch; f0 = passt_amd.PaSST.forward; c = torch.compile(net); "
+            "assert passt_amd.passt._OPAQUE['done'] and passt_amd.PaSST.forward is not f0 and 'torch._dynamo' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
 
 
 def test_torch_compile_leaves_the_forward_opaque():

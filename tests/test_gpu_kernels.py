@@ -350,9 +350,12 @@ def _attn_ref(qkv, B, H, N, scale, d_o=None):
     return o.detach(), lse.detach(), dqkv
 
 
-@pytest.mark.parametrize("pre", [0, 1])
+# `pre`: 0 = plain, 1 = PA_ATTN_Q_PRESCALED (backward: the library's choice), 3 = pre-scaled + PA_ATTN_BWD_TWO_PASS (the dQ + dK/dV
+# kernel pair), 5 = pre-scaled + PA_ATTN_BWD_SINGLE_PASS (the single-pass kernel: bf16, N <= 512; ignored elsewhere)
+@pytest.mark.parametrize("pre", [0, 1, 3, 5])
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
-@pytest.mark.parametrize("B,H,N", [(2, 2, 67), (1, 3, 474), (2, 12, 130), (1, 2, 1190), (3, 2, 64), (1, 1, 20)])
+@pytest.mark.parametrize("B,H,N", [(2, 2, 67), (1, 3, 474), (2, 12, 130), (1, 2, 1190), (3, 2, 64), (1, 1, 20),
+                                   (1, 2, 512), (2, 1, 500), (1, 1, 33), (1, 2, 96), (2, 2, 353)])
 def test_attention_fwd_bwd(dt, B, H, N, pre):
     D = H * 64
     x = rnd(B * N, 3 * D, seed=17, scale=1.5)
@@ -360,9 +363,9 @@ def test_attention_fwd_bwd(dt, B, H, N, pre):
     if N > 70:
         x[N - 3, 0:64] *= 4.0
         x[69, D:D + 64] = x[N - 3, 0:64]
-    qkv, qref = _attn_inputs(x, dt, D, pre)
+    qkv, qref = _attn_inputs(x, dt, D, pre & 1)
     scale = 0.125
-    o, lse = ops.attention_fwd(qkv, B, H, N, scale, flags=pre)
+    o, lse = ops.attention_fwd(qkv, B, H, N, scale, flags=pre & 1)
     d_o = rnd(B * N, D, seed=18).to(TD[dt]).to(DEV)
     ro, rlse, rdqkv = _attn_ref(qref, B, H, N, scale, d_o)
     e_o = rel_err(o, ro)
@@ -378,7 +381,7 @@ def test_attention_fwd_bwd(dt, B, H, N, pre):
     assert e_q < lim and e_k < lim and e_v < lim, (e_q, e_k, e_v)
 
 
-@pytest.mark.parametrize("pre", [0, 1])
+@pytest.mark.parametrize("pre", [0, 1, 3, 5])
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
 @pytest.mark.parametrize("case", ["rising", "falling", "spikes", "large", "tiny"])
 def test_attention_running_max_paths(dt, case, pre):
@@ -406,8 +409,8 @@ def test_attention_running_max_paths(dt, case, pre):
         x[:, :2 * D] *= 5.0
     elif case == "tiny":
         x[:, :2 * D] *= 1e-3
-    qkv, qref = _attn_inputs(x, dt, D, pre)
-    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=pre)
+    qkv, qref = _attn_inputs(x, dt, D, pre & 1)
+    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=pre & 1)
     d_o = rnd(B * N, D, seed=92).to(TD[dt]).to(DEV)
     ro, rlse, rdqkv = _attn_ref(qref, B, H, N, 0.125, d_o)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
@@ -425,7 +428,7 @@ def test_attention_running_max_paths(dt, case, pre):
     assert e_q < lim and e_k < lim and e_v < lim, (e_q, e_k, e_v)
 
 
-@pytest.mark.parametrize("pre", [0, 1])
+@pytest.mark.parametrize("pre", [0, 1, 3, 5])
 def test_attention_bit_deterministic_at_bench_shape(pre):
     """B = 64, H = 12, N = 474 (BASELINE config #2), bf16: four launches on the same input are bit-identical and finite, and
     eight sampled (clip, head) pairs of the full launch match the fp64 reference in value (forward and backward).  The
@@ -438,7 +441,7 @@ def test_attention_bit_deterministic_at_bench_shape(pre):
     d_o = torch.randn(B * N, D, device=DEV, generator=g).to(torch.bfloat16)
     ref = None
     for _ in range(4):
-        o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=pre)
+        o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=pre & 1)
         dq = ops.attention_bwd(qkv, o, d_o, lse, B, H, N, 0.125, flags=pre)
         assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all() and torch.isfinite(dq.float()).all()
         cur = (o.clone(), lse.clone(), dq.clone())

@@ -72,11 +72,13 @@ def check(path):
             # an LDS read may legitimately name a pending register only as its own destination AFTER the old value retired;
             # anything else touching an in-flight destination is the hazard
             if hit:
-                print(f"{path}:{ln}: [{kernel}] `{s}` touches v{sorted(hit)} while a ds_read_b64_tr_b16 into them is outstanding")
+                print(f"{path}:{ln}: [{kernel}] `{s}` touches v{sorted(hit)} while an LDS read into them is outstanding")
                 findings += 1
         if op.startswith("ds_"):
             dest = regs(operands[0]) if op.startswith("ds_read") or "rtn" in op else set()
-            queue.append((op == "ds_read_b64_tr_b16", dest, ln))
+            # every LDS read is tracked (round 5: the single-pass backward also issues its ds_read_b128 row fragments from asm; a
+            # compiler-issued read never trips this -- the compiler waits before it touches its own destinations)
+            queue.append((op.startswith("ds_read"), dest, ln))
         if op.startswith("s_load") or op.startswith("s_buffer_load") or op == "s_memtime":
             queue.append((False, set(), ln))       # SMEM shares lgkmcnt (returns out of order: only ever makes a wait stricter)
     return findings
