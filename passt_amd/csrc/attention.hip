@@ -867,9 +867,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #ifndef PA_FUSED_ABL
 #define PA_FUSED_ABL 0
 #endif
-#ifndef PA_FUSED_INTERLEAVE
-#define PA_FUSED_INTERLEAVE 0
-#endif
+
 static constexpr int FK = 512;                                   // key rows of the resident K tile (N <= FK)
 static constexpr int FT_PLANE = FK * 32;                         // one 16-query plane of T: FK keys x 16 queries x 2 B
 static constexpr int F_OFF_T = FK * 128;
@@ -914,24 +912,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nt = (N + 31) >> 5;                                // query tiles == key steps of phase 2
     constexpr int nk4 = FK / 32;                                 // phase 2 always walks all FK key rows (16 steps): rows up to there must be finite
 
-    // ---- prologue.  K rows -> sK and V rows -> the T region (8 rows per 1 KiB request, all FK rows, rows >= N as copies of row
-    // N - 1): the V rows are only there to be picked up as this wave's row fragments (coalesced LDS-DMA + ds_read_b128 instead of a
-    // lane-per-row walk through global memory), and they leave every byte of T FINITE -- phase 2 reads T rows no wave ever writes
-    // (keys in [32 nt, FK)) and multiplies them by the zero rows behind key N - 1 of the K tile
+    // ---- prologue.  K rows -> sK (8 rows per 1 KiB request, all FK rows, rows >= N as copies of row N - 1, zeroed below); T starts
+    // all-zero: phase 2 reads T rows no wave ever writes (keys in [32 nt, FK)) and multiplies them by the zero rows of K, so they
+    // must be finite.  (Measured and dropped, profiles/r05_attention_single_pass.txt: V rows through an LDS-DMA into the T region
+    // instead of the strided fragment loads below: +-0; per-query scalars from eight lanes per row + three cross-lane adds: +9 us.)
     {
         const char* gK = (const char*)(base + D);
-        const char* gV = (const char*)(base + 2 * D);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int rq = wave * 8 + i;
             const int row = rq * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz_f128(row);
-            const int64_t goff = (int64_t)min(row, N - 1) * ldbq + c * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gK + goff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gK + (int64_t)min(row, N - 1) * ldbq + c * 16),
                                              (__attribute__((address_space(3))) void*)(sK + rq * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gV + goff),
-                                             (__attribute__((address_space(3))) void*)(sT + rq * 1024), 16, 0, 0);
         }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4 * FT_PLANE / (512 * 16); ++i) *(u32x4*)(sT + (i * 512 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     // Q / dO tile t -> stage buffer: 8 requests of 8 rows, one per wave (waves 0-3: Q, 4-7: dO)
     const int st_tensor = wave >> 2, st_piece = wave & 3;
@@ -946,29 +943,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     stage(0);
     const int kbase0 = wave * 64;
-    F vf[2][NF];                                                 // filled after the first barrier
+    F vf[2][NF];                                                 // V row fragments of this wave's keys (B operand of the dP products)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow = min(kbase0 + kb * 32 + l31, N - 1);
+#pragma unroll
+        for (int s = 0; s < NF; ++s) vf[kb][s] = *(const F*)(base + 2 * D + (int64_t)krow * ldqkv + (s * 2 + hf) * 8);
+    }
     // per-query scalars in the form the score chains take as C operand: -lse * log2(e), -delta = -rowsum(dO * O).  Wave w owns
-    // queries [64 w, 64 w + 64): eight lanes per row, 16 bytes each (full 128-byte lines: a lane-per-row walk of the same rows costs
-    // the texture path 8 x as many line requests -- the prologue is not overlapped with anything, one workgroup per CU)
+    // queries [64 w, 64 w + 64).  Queries past N (last tile; their Q / dO rows are copies of row N - 1) get the C operand -inf:
+    // P = exp2(-inf) = 0 and dS = P * finite = 0 -- they contribute nothing to dK / dV and no tile needs a mask.
+    {
+        // two lanes per row (what the dQ kernel of the two-kernel backward does)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = wave * 64 + i * 8 + (lane >> 3);
-        if (wave * 64 + i * 8 < nt * 32) {                       // wave-uniform
-            const int qrow = min(q, N - 1);
-            const int off = (lane & 7) * 8;
-            const F df = *(const F*)(dobase + (int64_t)qrow * ldo + off);
-            const F of = *(const F*)(obase + (int64_t)qrow * ldo + off);
-            float dlt = 0.f;
+        for (int r = 0; r < 2; ++r) {
+            const int q = wave * 64 + r * 32 + l31;
+            if (wave * 64 + r * 32 < nt * 32) {                  // wave-uniform
+                const int qrow = min(q, N - 1);
+                float dlt = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dlt = fmaf((float)df[e], (float)of[e], dlt);
-            dlt += __shfl_xor(dlt, 1);
-            dlt += __shfl_xor(dlt, 2);
-            dlt += __shfl_xor(dlt, 4);
-            // queries past N (last tile; their Q / dO rows are copies of row N - 1): C operand -inf, so P = exp2(-inf) = 0 and
-            // dS = P * finite = 0 -- they contribute nothing to dK / dV and no tile needs a mask
-            if ((lane & 7) == 0) {
-                sDelta[q] = -dlt;
-                sLse[q] = q < N ? -lse[(int64_t)bh * N + qrow] * LOG2E : -INFINITY;
+                for (int s = 0; s < NF; ++s) {
+                    const int off = (s * 2 + hf) * 8;
+                    const F df = *(const F*)(dobase + (int64_t)qrow * ldo + off);
+                    const F of = *(const F*)(obase + (int64_t)qrow * ldo + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dlt = fmaf((float)df[e], (float)of[e], dlt);
+                }
+                dlt += other_half(dlt);
+                if (lane < 32) {
+                    sDelta[q] = -dlt;
+                    sLse[q] = q < N ? -lse[(int64_t)bh * N + qrow] * LOG2E : -INFINITY;
+                }
             }
         }
     }
@@ -1059,16 +1064,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int st = 0; st < NF; ++st) {
                 frag_settle1(df[st], NF - 1 - st + ((PA_FUSED_ABL & 4) ? 0 : 8));
                 mma32<T>(dpa, df[st], vf[kb][st]);
-#if PA_FUSED_INTERLEAVE
-                // the exponentials of four score rows behind each MFMA of the dP chain (in ONE wave VALU work issued behind an
-                // MFMA runs in its shadow; across waves it does not: profiles/r04_mfma_valu_arbitration.txt)
-                if (!(PA_FUSED_ABL & 2)) {
-#pragma unroll
-                    for (int r = 4 * st; r < 4 * st + 4; ++r) sa[r] = __builtin_amdgcn_exp2f(sa[r]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
-                }
-#endif
             }
         } else if (!(PA_FUSED_ABL & 4)) {
             issue_cf(0);
@@ -1076,9 +1071,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!(PA_FUSED_ABL & 2)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#if !PA_FUSED_INTERLEAVE
                 sa[r] = __builtin_amdgcn_exp2f(sa[r]);
-#endif
                 dpa[r] *= sa[r];                                // dS / scale
             }
         }
@@ -1157,11 +1150,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // V row fragments of this wave's keys (B operand of the dP products), from the V rows parked in the T region
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int st = 0; st < NF; ++st) vf[kb][st] = ld128(lds0 + F_OFF_T + (kbase0 + kb * 32) * 128 + lo.rowf[st]);
     // K rows behind the last key := 0 (so that the dS columns of lanes past N, and the T rows nobody writes, contribute nothing
     // to dQ); the scores of those lanes become exp2(-lse): finite
     for (int i = tid; i < (nk4 * 32 - N) * 8; i += 512) {
