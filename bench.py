@@ -76,7 +76,8 @@ CONFIGS = {
 }
 
 
-PROFILE_EVERY = 5      # timed steps between two steps that carry per-launch HIP events
+PROFILE_EVERY = 10     # timed steps between two steps that carry per-launch HIP events (two event records per launch cost the
+                       # instrumented step ~6 %: r04 sampled 1 step in 5, r05 samples 1 in 10 -- steps 0 and 10 of the default 20)
 
 
 def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
@@ -633,7 +634,7 @@ def run(args):
         gc.freeze()
         if getattr(ts, "phases", None) is not None:
             ts.phases.clear()                   # phase diagnostics: timed steps only (warm-up carries one-time module loads)
-        # per-launch HIP events on the GEMM family (roofline): two event records per launch cost ~3.4 % of the step
+        # per-launch HIP events on the GEMM family (roofline): two event records per launch cost several % of the step
         # when every step is instrumented, so one timed step in PROFILE_EVERY carries them (always including step 0)
         prof = {} if (rank == 0 and not args.no_roofline and not args.graph) else None
         t0 = time.perf_counter()
