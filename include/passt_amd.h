@@ -122,6 +122,13 @@ int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gam
                      const float* mean, const float* rstd, const float* dres, float* dx,
                      void* dx_lp, float* dgamma, float* dbeta, float* dcolsum, int accumulate, float* ws,
                      int M, int D, void* stream);
+/* The same without the finishing launch (ABI 5): dx / dx_lp are complete, the parameter gradients stay as
+ * pa_layernorm_bwd_rows(M) partial rows ws[row][3][D] = {dgamma | dbeta | column sums of dx}; the caller reduces them with
+ * pa_reduce_partials_batched (PA_REDUCE_ROWS, pitch 3 D) -- together with the block's other finishing reductions. */
+int pa_layernorm_bwd_rows(int M);
+int pa_layernorm_bwd_partial(const void* dy, int dtype, const float* x, const float* gamma,
+                             const float* mean, const float* rstd, const float* dres, float* dx,
+                             void* dx_lp, float* ws, int M, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[M][N] = A[M][K] * B[N][K]^T  (both operands K-contiguous), MFMA, f32 accumulation.
@@ -194,6 +201,10 @@ typedef struct {
  * Bit-identical results; measured slower in the training step (partial-line stores), kept for A/B measurements and the
  * equality test.  PA_EPILOGUE_V3=1 in the environment selects it process-wide. */
 #define PA_GEMM_EPILOGUE_V3 0x1000
+/* PA_EPI_DGELU with colsum_out (ABI 5): leave the column sums as partial rows in colsum_ws (one per wave tile) and skip the
+ * finishing launch; pa_gemm_last_colsum_rows() (the calling thread's last such call) says how many rows were written, the caller
+ * reduces them with pa_reduce_partials_batched (PA_REDUCE_ROWS, pitch N).  colsum_out must still be non-NULL (it is not written). */
+#define PA_GEMM_COLSUM_DEFER 0x2000
 int pa_gemm_blocked_pre_ok(int M, int N, int K);
 int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);
@@ -238,16 +249,29 @@ int pa_zero2d(void* ptr, int64_t pitch_bytes, int64_t width_bytes, int64_t rows,
 /* out[i] = (accumulate ? out[i] : 0) + sum_z partial[z][i], i < n */
 int pa_reduce_partials(const float* partial, int splits, int64_t n, float* out, int accumulate,
                        void* stream);
-/* the same for up to PA_REDUCE_BATCH_MAX slab sets in one launch (`d` is a HOST array) */
-#define PA_REDUCE_BATCH_MAX 8
+/* the same for up to PA_REDUCE_BATCH_MAX reductions in one launch (`d` is a HOST array).  Two forms (ABI 5):
+ *   mode PA_REDUCE_SLABS (0): out[i] (+)= sum_{z < splits} partial[z * n + i], i < n -- few slices of a long vector (the split-K
+ *                             slabs of the weight gradients); 16-byte accesses, one thread per four outputs;
+ *   mode PA_REDUCE_ROWS  (1): out[c] (+)= sum_{r < splits} partial[r * pitch + c], c < n -- MANY short rows (the per-workgroup
+ *                             partial rows of pa_layernorm_bwd_partial, the per-wave-tile rows of a deferred PA_EPI_DGELU column
+ *                             sum): 16 columns x 16 row groups per workgroup, four loads in flight per thread.
+ * One launch per transformer block finishes all of its parameter gradients: four weight gradients + qkv.bias (slabs), two
+ * LayerNorms' dgamma | dbeta and the bias gradient each of them carries, fc1.bias (rows). */
+#define PA_REDUCE_BATCH_MAX 12
+#define PA_REDUCE_SLABS 0
+#define PA_REDUCE_ROWS 1
 typedef struct pa_reduce_desc {
     const float* partial;
     float* out;
     int64_t n;
     int32_t splits;
     int32_t accumulate;
+    int64_t pitch;         /* PA_REDUCE_ROWS: floats between two rows of `partial` (SLABS: ignored, the slices are dense) */
+    int32_t mode;
+    int32_t reserved;
 } pa_reduce_desc;
 int pa_reduce_partials_batched(const pa_reduce_desc* d, int n, void* stream);
+int pa_gemm_last_colsum_rows(void);
 /* out[r] = (accumulate ? out[r] : 0) + sum_c in[r][c], c < C  (bias gradients from dY^T) */
 int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float* out, int accumulate,
               void* stream);

@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
 
 
 class ReduceDesc(C.Structure):         # == pa_reduce_desc
-    _fields_ = [("partial", vp), ("out", vp), ("n", i64), ("splits", i32), ("accumulate", i32)]
+    _fields_ = [("partial", vp), ("out", vp), ("n", i64), ("splits", i32), ("accumulate", i32), ("pitch", i64), ("mode", i32),
+                ("reserved", i32)]
 
 
 class StageDesc(C.Structure):          # == pa_stage_desc
@@ -56,6 +57,9 @@ SIGNATURES = {
     "pa_layernorm_fwd": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
     "pa_layernorm_bwd_ws_floats": (i64, [i32, i32]),
     "pa_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "pa_layernorm_bwd_rows": (i32, [i32]),
+    "pa_layernorm_bwd_partial": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "pa_gemm_last_colsum_rows": (i32, []),
     "pa_gemm_colsum_ws_floats": (i64, [i32, i32]),
     "pa_gemm_blocked_pre_ok": (i32, [i32, i32, i32]),
     "pa_gemm_blocked_pre_elems": (i64, [i32, i32]),
@@ -103,6 +107,8 @@ SIGNATURES = {
 }
 GEMM_BLOCKED_PRE = 0x100      # pa_gemm_args.reserved flags (include/passt_amd.h)
 GEMM_NO_PERSIST = 0x400
+GEMM_COLSUM_DEFER = 0x2000    # PA_EPI_DGELU column sums stay as partial rows for the block's one finishing launch
+REDUCE_SLABS, REDUCE_ROWS = 0, 1    # pa_reduce_desc.mode
 GEMM_EPILOGUE_V3 = 0x1000     # run a pa_gemm_nt call with the LDS-free epilogue (A/B, equality test; slower: opt-in)
 COMM_ID_BYTES = 128
 

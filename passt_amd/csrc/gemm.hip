@@ -2559,7 +2559,12 @@ extern "C" int pa_rowsum(const void* in, int dtype, int R, int C, int ld, float*
     return check_launch();
 }
 
+static thread_local int t_last_colsum_rows = 0;
+extern "C" int pa_gemm_last_colsum_rows(void) { return t_last_colsum_rows; }
+
 static int pa::finish_gemm_colsum(const pa_gemm_args& a, int rows, hipStream_t st) {
+    t_last_colsum_rows = rows;
+    if (a.reserved & PA_GEMM_COLSUM_DEFER) return PA_OK;       // the caller reduces the rows (pa_reduce_partials_batched)
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)cdiv(a.N, 64)), dim3(256), 0, st, a.colsum_ws, rows, a.N, a.N, a.colsum_out,
                        a.colsum_accumulate);
     return check_launch();
@@ -2649,9 +2654,38 @@ struct ReduceBatch {
     pa_reduce_desc d[PA_REDUCE_BATCH_MAX];
     int32_t n;
 };
-// blockIdx.y = problem; same arithmetic (and summation order) as reduce_partials_kernel
+// blockIdx.y = problem.  SLABS: same arithmetic (and summation order) as reduce_partials_kernel.  ROWS: the arithmetic of
+// ln_bwd_reduce_kernel (layernorm.hip): 16 columns x 16 row groups per workgroup, four loads in flight, then a 16-way tree in LDS.
 __global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const ReduceBatch b) {
     const pa_reduce_desc& d = b.d[blockIdx.y];
+    if (d.mode == PA_REDUCE_ROWS) {
+        __shared__ float red[16][17];
+        const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+        for (int64_t c0 = (int64_t)blockIdx.x * 16; c0 < d.n; c0 += (int64_t)gridDim.x * 16) {     // workgroup-uniform
+            const int64_t k = c0 + cx;
+            float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (k < d.n) {
+                int r = ry;
+                for (; r + 48 < d.splits; r += 64) {
+                    s += d.partial[(int64_t)r * d.pitch + k];
+                    s1 += d.partial[(int64_t)(r + 16) * d.pitch + k];
+                    s2 += d.partial[(int64_t)(r + 32) * d.pitch + k];
+                    s3 += d.partial[(int64_t)(r + 48) * d.pitch + k];
+                }
+                for (; r < d.splits; r += 16) s += d.partial[(int64_t)r * d.pitch + k];
+            }
+            red[ry][cx] = (s + s1) + (s2 + s3);
+            __syncthreads();
+            if (ry == 0 && k < d.n) {
+                float t = 0.f;
+#pragma unroll
+                for (int y = 0; y < 16; ++y) t += red[y][cx];
+                d.out[k] = (d.accumulate ? d.out[k] : 0.f) + t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int64_t n = d.n, n4 = (n % 4 == 0 && (((uintptr_t)d.partial | (uintptr_t)d.out) & 15) == 0) ? n / 4 : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < n4; i += stride) {
@@ -2670,15 +2704,16 @@ __global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const Redu
 extern "C" int pa_reduce_partials_batched(const pa_reduce_desc* d, int n, void* stream) {
     if (!d || n < 1 || n > PA_REDUCE_BATCH_MAX) return PA_EINVAL;
     ReduceBatch b;
-    int64_t nmax = 0;
+    int64_t blocks = 1;
     for (int p = 0; p < n; ++p) {
         if (!d[p].partial || !d[p].out || d[p].splits < 1 || d[p].n <= 0) return PA_EINVAL;
+        if (d[p].mode != PA_REDUCE_SLABS && d[p].mode != PA_REDUCE_ROWS) return PA_EINVAL;
+        if (d[p].mode == PA_REDUCE_ROWS && d[p].pitch < d[p].n) return PA_EINVAL;
         b.d[p] = d[p];
-        nmax = std::max<int64_t>(nmax, d[p].n);
+        blocks = std::max<int64_t>(blocks, d[p].mode == PA_REDUCE_ROWS ? cdiv(d[p].n, 16) : cdiv(cdiv(d[p].n, 4), 256));
     }
     b.n = n;
-    const int blocks = (int)std::min<int64_t>(cdiv(cdiv(nmax, 4), 256), 2048);
-    hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3((unsigned)std::min<int64_t>(blocks, 2048), n), dim3(256), 0, (hipStream_t)stream, b);
     return check_launch();
 }
 

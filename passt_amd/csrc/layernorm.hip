@@ -3,6 +3,7 @@
 // norm (:450,:570) and head.0 (:463, eps 1e-5).  HBM-bound: every row is read once with float4
 // loads, kept in registers for the two-pass mean/variance (torch's biased variance), written once.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pa_common.h"
 
@@ -203,9 +204,31 @@ extern "C" int pa_layernorm_fwd(const float* x, const float* gamma, const float*
     return check_launch();
 }
 
-static int ln_bwd_blocks(int M) { return (int)std::min<int64_t>(LN_BWD_BLOCKS, cdiv(M, 4)); }
+// workgroups of the backward kernel (= partial rows its finishing reduction reads): at most 1024, at least two rows per wave
+// (round 5, ESC-50 at batch 12, M = 4 236: 530 workgroups instead of 1 024 -- half the partial rows to write and reduce -- is
+// + 0.9 % on that step; four rows per wave - 2 %: too few waves in flight).  PA_LN_BWD_BLOCKS / PA_LN_BWD_ROWS_PER_WAVE
+// (environment, read once): A/B knobs
+static int ln_bwd_blocks(int M) {
+    static const int cap = [] { const char* e = getenv("PA_LN_BWD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : LN_BWD_BLOCKS; }();
+    static const int rpw = [] { const char* e = getenv("PA_LN_BWD_ROWS_PER_WAVE"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cap, cdiv(M, 4 * rpw)));
+}
 
 extern "C" int64_t pa_layernorm_bwd_ws_floats(int M, int D) { return (int64_t)ln_bwd_blocks(M) * 3 * D; }
+
+extern "C" int pa_layernorm_bwd_rows(int M) { return M > 0 ? ln_bwd_blocks(M) : 0; }
+
+static int ln_bwd_launch(const void* dy, int dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* dres, float* dx, void* dx_lp, float* ws, int M, int D, hipStream_t st);
+
+extern "C" int pa_layernorm_bwd_partial(const void* dy, int dtype, const float* x, const float* gamma,
+                                        const float* mean, const float* rstd, const float* dres, float* dx,
+                                        void* dx_lp, float* ws, int M, int D, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !ws || M <= 0 || D <= 0) return PA_EINVAL;
+    if (D % 4 || D > LN_MAXV * 256) return PA_EUNSUPPORTED;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    return ln_bwd_launch(dy, dtype, x, gamma, mean, rstd, dres, dx, dx_lp, ws, M, D, (hipStream_t)stream);
+}
 
 extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
@@ -213,10 +236,18 @@ extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const
                                 int M, int D, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || M <= 0 || D <= 0) return PA_EINVAL;
     if (D % 4 || D > LN_MAXV * 256) return PA_EUNSUPPORTED;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ln_bwd_launch(dy, dtype, x, gamma, mean, rstd, dres, dx, dx_lp, ws, M, D, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(3 * D, 16)), dim3(256), 0, st, ws, ln_bwd_blocks(M), D, dgamma, dbeta, dcolsum, accumulate);
+    return check_launch();
+}
+
+static int ln_bwd_launch(const void* dy, int dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* dres, float* dx, void* dx_lp, float* ws, int M, int D, hipStream_t st) {
     const int nblk = ln_bwd_blocks(M);
     const size_t lds = (size_t)12 * D * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
     const int nvl = (int)cdiv(D, 256);
 #define PA_LN_BWD(V)                                                                                              \
     do {                                                                                                          \
@@ -226,8 +257,5 @@ extern "C" int pa_layernorm_bwd(const void* dy, int dtype, const float* x, const
     if (nvl <= 1) PA_LN_BWD(1); else if (nvl == 2) PA_LN_BWD(2); else if (nvl == 3) PA_LN_BWD(3);
     else if (nvl == 4) PA_LN_BWD(4); else PA_LN_BWD(8);
 #undef PA_LN_BWD
-    int rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv(3 * D, 16)), dim3(256), 0, st, ws, nblk, D, dgamma, dbeta, dcolsum, accumulate);
     return check_launch();
 }

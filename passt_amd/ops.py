@@ -236,14 +236,25 @@ def layernorm_fwd(x, gamma, beta, eps, dtype, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumulate=False, dcolsum=None):
-    """Returns (dx f32, dx_lp or None).  dgamma/dbeta (and dcolsum = column sums of dx, if given) are written in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumulate=False, dcolsum=None, defer=None):
+    """Returns (dx f32, dx_lp or None).  dgamma/dbeta (and dcolsum = column sums of dx, if given) are written in place.
+    defer: a list -- the parameter gradients stay as partial rows and (partial, rows, pitch, n, out) jobs are appended to it for
+    the block's ONE finishing launch (wgrad_tn_batched(..., row_jobs=defer)) instead of a reduction launch per LayerNorm."""
     M, D = x.shape
     dtype = PA_DTYPE[dy.dtype]
     lib = _lib.load()
     dx = torch.empty((M, D), device=x.device, dtype=torch.float32)
     dx_lp = torch.empty((M, D), device=x.device, dtype=dy.dtype) if (want_lp and dtype != PA_F32) else None
     ws = torch.empty(lib.pa_layernorm_bwd_ws_floats(M, D), device=x.device, dtype=torch.float32)
+    if defer is not None and not accumulate:
+        check(lib.pa_layernorm_bwd_partial(_p(dy), dtype, _p(x, torch.float32), _p(gamma, torch.float32), _p(mean, torch.float32),
+                                           _p(rstd, torch.float32), _p(dres, torch.float32), _p(dx), _p(dx_lp), _p(ws), M, D, _stream()),
+              "pa_layernorm_bwd_partial")
+        rows = lib.pa_layernorm_bwd_rows(M)
+        for j, out in enumerate((dgamma, dbeta, dcolsum)):
+            if out is not None:
+                defer.append((ws[j * D:], rows, 3 * D, D, out))
+        return dx, (dx if dtype == PA_F32 else dx_lp)
     check(lib.pa_layernorm_bwd(_p(dy), dtype, _p(x, torch.float32), _p(gamma, torch.float32), _p(mean, torch.float32), _p(rstd, torch.float32), _p(dres, torch.float32), _p(dx), _p(dx_lp),
                                _p(dgamma), _p(dbeta), _p(dcolsum), int(accumulate), _p(ws), M, D, _stream()),
           "pa_layernorm_bwd")
@@ -375,14 +386,18 @@ def linear_gelu(x_lp, W_lp, bias, dtype):
     return pre, act
 
 
-def dgelu_gemm(dy_lp, Wt_lp, pre, dtype, colsum_out=None, colsum_ws=None):
+def dgelu_gemm(dy_lp, Wt_lp, pre, dtype, colsum_out=None, colsum_ws=None, defer=None):
     """d_pre[M][N] = (dy Wt^T) * gelu'(pre): the input gradient of fc2 times the GELU derivative; pre as returned by
-    linear_gelu (row-major tensor or BlockedPre)."""
+    linear_gelu (row-major tensor or BlockedPre).  defer (a list, with colsum_out): the column sums stay as one partial row per
+    wave tile in colsum_ws and a (partial, rows, pitch, n, out) job is appended for the block's finishing launch."""
     blocked = isinstance(pre, BlockedPre)
     M, N = pre.shape
     d_pre = torch.empty((M, N), device=dy_lp.device, dtype=TORCH_DTYPE[dtype])
+    deferred = defer is not None and colsum_out is not None
     gemm_nt(dy_lp, Wt_lp, dtype, EPI_DGELU, aux=pre.buf.view(-1, N) if blocked else pre, out_lp=d_pre,
-            colsum_out=colsum_out, colsum_ws=colsum_ws, flags=GEMM_BLOCKED_PRE if blocked else 0)
+            colsum_out=colsum_out, colsum_ws=colsum_ws, flags=(GEMM_BLOCKED_PRE if blocked else 0) | (_lib.GEMM_COLSUM_DEFER if deferred else 0))
+    if deferred:
+        defer.append((colsum_ws, _lib.load().pa_gemm_last_colsum_rows(), N, N, colsum_out))
     return d_pre
 
 
@@ -515,10 +530,12 @@ def wgrad_tn_fuses_bias(dtype):
     return dtype == PA_BF16 and GEMM_TUNE != 1
 
 
-def wgrad_tn_batched(problems, dtype, partial_ws=None):
+def wgrad_tn_batched(problems, dtype, partial_ws=None, row_jobs=None):
     """problems: up to 4 of (dY [M][N], X [M][K], out [N][K] f32, accumulate[, db [N] f32 or None]): all weight gradients of a
-    block in ONE pa_gemm_tn_batched launch + ONE batched split-K reduction.  A problem with db also gets its bias gradient
-    (column sums of dY) out of the same launch.  Returns the (possibly grown) partial workspace."""
+    block in ONE pa_gemm_tn_batched launch + ONE batched finishing reduction.  A problem with db also gets its bias gradient
+    (column sums of dY) out of the same launch.  row_jobs: (partial, rows, pitch, n, out) reductions of many short partial rows
+    (deferred LayerNorm / GELU' parameter gradients of the block, see layernorm_bwd / dgelu_gemm) that ride in the same finishing
+    launch.  Returns the (possibly grown) partial workspace."""
     from ._lib import ReduceDesc
     assert dtype == PA_BF16 and 1 <= len(problems) <= 4
     problems = [tuple(p) + (None,) * (5 - len(p)) for p in problems]
@@ -531,7 +548,8 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
     need = sum(S * m[1] * (m[2] + (1 if p[4] is not None else 0)) for S, m, p in zip(splits, metas, problems))
     if partial_ws is None or partial_ws.numel() < need:
         partial_ws = torch.empty(need, device=problems[0][0].device, dtype=torch.float32)
-    nred = len(problems) + sum(1 for p in problems if p[4] is not None)
+    row_jobs = row_jobs or []
+    nred = len(problems) + sum(1 for p in problems if p[4] is not None) + len(row_jobs)
     args = (GemmArgs * len(problems))()
     red = (ReduceDesc * nred)()
     off, flops, k = 0, 0.0, len(problems)
@@ -553,6 +571,11 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None):
             k += 1
             rb.partial, rb.out, rb.n, rb.splits, rb.accumulate = _p(bpart), _p(db, torch.float32), N, S, int(acc)
         flops += 2.0 * N * K * Mtok
+    for part_rows, rows, pitch, n, out in row_jobs:
+        rb = red[k]
+        k += 1
+        rb.partial, rb.out, rb.n, rb.splits, rb.accumulate = _p(part_rows, torch.float32, True), _p(out, torch.float32), n, rows, 0
+        rb.pitch, rb.mode = pitch, _lib.REDUCE_ROWS
     lib = _lib.load()
     ev0 = ev1 = None
     if GEMM_PROFILE is not None:        # the bracket covers the batched split-K reduction too

@@ -407,6 +407,10 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
     # bf16, single stream: the four weight gradients of a block wait until the block's last operand exists and go out as
     # ONE batched launch (+ one batched split-K reduction): no drain / prologue between them, equal-sized work items
     pending = [] if (dt == PA_BF16 and not side.enabled and not os.environ.get("PASST_AMD_NO_BATCH_WGRAD")) else None
+    # ... and so do the block's small finishing reductions: the two LayerNorms' dgamma | dbeta (+ the bias gradient each carries)
+    # and the GELU' epilogue's fc1.bias rows stay as partial rows and are reduced by the SAME finishing launch as the split-K
+    # slabs (three launches per block less; PASST_AMD_NO_DEFER_ROWS=1: A/B, every reduction right behind its producer)
+    rowjobs = [] if (pending is not None and not os.environ.get("PASST_AMD_NO_DEFER_ROWS")) else None
     # PASST_AMD_BIAS_FROM_WGRAD=1 (A/B; required by PA_EPILOGUE_V3=1): fc1.bias out of the weight-gradient launch instead of the
     # GELU' epilogue's lane-local column sums
     bias_from_wgrad = (dt == PA_BF16 and ops.wgrad_tn_fuses_bias(dt) and not os.environ.get("PASST_AMD_NO_FUSED_BIAS")
@@ -423,8 +427,10 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         if db is not None and not fused_bias:
             ops.colsum(dY, db)
         if done is not None:
-            scratch["part"] = ops.wgrad_tn_batched(pending, dt, scratch.get("part"))
+            scratch["part"] = ops.wgrad_tn_batched(pending, dt, scratch.get("part"), row_jobs=rowjobs)
             pending.clear()
+            if rowjobs is not None:
+                rowjobs.clear()
             if on_block_done:
                 on_block_done(done)
 
@@ -459,13 +465,13 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
             # the fc1.bias gradient (column sums of d_pre) comes out of the GELU' epilogue
             cws = scratch["colsum_ws"] = ops.gemm_colsum_ws(h_pre.shape[0], h_pre.shape[1], dx_lp.device, scratch.get("colsum_ws"))
             d_pre = ops.dgelu_gemm(dx_lp, st.get(blk.mlp.fc2.weight, dt, True), h_pre, dt,
-                                   colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws)
+                                   colsum_out=g[pfx + "mlp.fc1.bias"], colsum_ws=cws, defer=rowjobs)
             wgrad(d_pre, ln2, g[pfx + "mlp.fc1.weight"], None)
         d_ln2 = torch.empty_like(ln2)
         ops.gemm_nt(d_pre, st.get(blk.mlp.fc1.weight, dt, True), dt, EPI_STORE, out_lp=d_ln2)
         del d_pre
         dx, dx_lp = ops.layernorm_bwd(d_ln2, x_mid, blk.norm2.weight, mean2, rstd2, dx, g[pfx + "norm2.weight"],
-                                      g[pfx + "norm2.bias"], True, dcolsum=g[pfx + "attn.proj.bias"])
+                                      g[pfx + "norm2.bias"], True, dcolsum=g[pfx + "attn.proj.bias"], defer=rowjobs)
         # ---- attention:  x_mid = x_in + proj(attn(qkv(LN1(x_in))))      (proj.bias gradient came out of LN2' above)
         wgrad(dx_lp, att, g[pfx + "attn.proj.weight"], None)
         d_att = torch.empty_like(att)
@@ -481,7 +487,7 @@ def _passt_backward(model, ctx, dlogits, dfeat, grads, on_block_done=None):
         ops.gemm_nt(d_qkv, st.get(blk.attn.qkv.weight, dt, True), dt, EPI_STORE, out_lp=d_ln1)
         dx, dx_lp = ops.layernorm_bwd(d_ln1, xs, blk.norm1.weight, mean1, rstd1, dres, g[pfx + "norm1.weight"],
                                       g[pfx + "norm1.bias"], i > 0,
-                                      dcolsum=g[f"blocks.{i - 1}.mlp.fc2.bias"] if i > 0 else None)
+                                      dcolsum=g[f"blocks.{i - 1}.mlp.fc2.bias"] if i > 0 else None, defer=rowjobs)
         # last weight gradient of the block; the side stream (ordered after the LayerNorm gradients above)
         # then reports the block complete, so its all-reduce bucket starts without stalling the main stream
         wgrad(d_qkv, ln1, g[pfx + "attn.qkv.weight"], g[pfx + "attn.qkv.bias"], done=i)

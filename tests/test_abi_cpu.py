@@ -35,7 +35,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.pa_abi_version() == 5
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
-    assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768
+    assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768 and lib.pa_layernorm_bwd_rows(30336) == 1024
+    assert lib.pa_layernorm_bwd_rows(4236) == 530 and lib.pa_layernorm_bwd_ws_floats(4236, 768) == 530 * 3 * 768
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -45,11 +46,11 @@ def test_ctypes_structs_match_the_c_layout():
 #include <stddef.h>
 #include "passt_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
          offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
          offsetof(pa_gemm_args, tune), sizeof(pa_mel_params), offsetof(pa_gemm_args, colsum_out),
          offsetof(pa_gemm_args, colsum_accumulate), sizeof(pa_stage_desc), offsetof(pa_gemm_args, colscale_n),
-         offsetof(pa_gemm_args, colscale));
+         offsetof(pa_gemm_args, colscale), sizeof(pa_reduce_desc), offsetof(pa_reduce_desc, pitch), offsetof(pa_reduce_desc, mode));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -59,7 +60,8 @@ int main(void) {
     G = _lib.GemmArgs
     got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
            G.tune.offset, ctypes.sizeof(_lib.MelParams), G.colsum_out.offset, G.colsum_accumulate.offset,
-           ctypes.sizeof(_lib.StageDesc), G.colscale_n.offset, G.colscale.offset]
+           ctypes.sizeof(_lib.StageDesc), G.colscale_n.offset, G.colscale.offset, ctypes.sizeof(_lib.ReduceDesc),
+           _lib.ReduceDesc.pitch.offset, _lib.ReduceDesc.mode.offset]
     assert got == [int(v) for v in out]
 
 

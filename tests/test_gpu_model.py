@@ -654,6 +654,40 @@ def test_config2_batch64_vs_reference_golden(golden_dir, name, precision):
            worst_grad_trainstep=w_t, worst_grad_norm_trainstep=wn_t)
 
 
+def test_block_finishing_launch_equals_separate_reductions():
+    """Round 5: the two LayerNorms' dgamma | dbeta (+ the bias gradient each carries) and the GELU' epilogue's fc1.bias rows of a
+    block are reduced by the SAME finishing launch as the split-K slabs of its weight gradients (pa_reduce_partials_batched,
+    PA_REDUCE_ROWS) instead of three launches of their own.  Against PASST_AMD_NO_DEFER_ROWS=1 on the same draws: every
+    LayerNorm gradient and the bias gradients they carry bit-identical (same arithmetic, other launch), fc1.bias to f32 rounding
+    (the row reduction sums in another order than pa_colsum_f32), everything else bit-identical."""
+    case = G.BIG_CASES["model_passt_s_train_full"]
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    grads = []
+    for knob in ("1", None):
+        if knob:
+            os.environ["PASST_AMD_NO_DEFER_ROWS"] = knob
+        else:
+            os.environ.pop("PASST_AMD_NO_DEFER_ROWS", None)
+        try:
+            m = build(case, "bf16").train()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.manual_seed(case["torch_seed"])
+                logits, _ = m(xg)
+                torch.nn.functional.binary_cross_entropy_with_logits(logits, yg, reduction="none").mean().backward()
+            grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("PASST_AMD_NO_DEFER_ROWS", None)
+    sep, merged = grads
+    assert sep.keys() == merged.keys()
+    for k in sep:
+        if k.endswith("mlp.fc1.bias"):
+            assert rel(merged[k].cpu(), sep[k].cpu()) < 2e-6, k
+        else:
+            assert torch.equal(merged[k], sep[k]), k
+
+
 def test_model_speed_test_flow():
     """The reference's own caller flow (ex_audioset.py:121-135 and model_speed_test :364-426) on the drop-in module:
     ``torch.compile(net)``, ``torch.cuda.amp.autocast()`` (fp16), ``GradScaler``, ``SGD(net.parameters(), lr=1e-3)``,
