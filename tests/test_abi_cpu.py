@@ -74,6 +74,23 @@ def test_argument_validation_without_gpu():
     assert lib.pa_layernorm_fwd(None, None, None, None, 0, None, None, 4, 4, 1e-6, None) == -1
     p = _lib.MelParams()
     assert lib.pa_mel_frontend_fwd(None, 1, 100, None, None, None, None, ctypes.byref(p), None) == -1
+    # ABI 5: the attention-backward form flags are validated before anything is launched; unknown bits are an error
+    buf = (ctypes.c_float * 64)()
+    q = ctypes.cast(buf, ctypes.c_void_p)
+    for flags, want in ((8, -1), (1 | 16, -1)):
+        assert lib.pa_attention_bwd(q, 192, q, q, 64, q, q, q, 192, 1, 1, 4, 4, ctypes.c_float(0.125), 1, flags, None) == want
+    assert lib.pa_attention_fwd(q, 192, q, 64, q, 1, 1, 4, 4, ctypes.c_float(0.125), 1, 2, None) == -1      # backward-only flag
+    # the batched finishing reduction: mode / pitch / count checks
+    d = (_lib.ReduceDesc * 13)()
+    for e in d:
+        e.partial, e.out, e.n, e.splits, e.mode, e.pitch = q, q, 16, 2, _lib.REDUCE_ROWS, 16
+    assert lib.pa_reduce_partials_batched(d, 13, None) == -1                   # > PA_REDUCE_BATCH_MAX
+    d[0].mode = 7
+    assert lib.pa_reduce_partials_batched(d, 1, None) == -1
+    d[0].mode, d[0].pitch = _lib.REDUCE_ROWS, 8                               # rows shorter than n
+    assert lib.pa_reduce_partials_batched(d, 1, None) == -1
+    assert lib.pa_layernorm_bwd_partial(None, 1, None, None, None, None, None, None, None, None, 4, 4, None) == -1
+    assert lib.pa_layernorm_bwd_rows(0) == 0 and lib.pa_layernorm_bwd_rows(7) == 1
 
 
 def test_product_path_has_no_cpu_fallback():
