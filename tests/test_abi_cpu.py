@@ -302,3 +302,12 @@ def test_attention_isa_never_touches_in_flight_lds_fragments():
                         os.path.join(src, "attention.hip"), "-o", out], check=True, capture_output=True)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_asm.py"), out], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_single_pass_attention_backward_index_math_on_the_cpu():
+    """tools/emulate_attn_bwd_fused.py: the transposition buffer T of attn_bwd_fused_kernel (phase-1 write addresses, XOR swizzle)
+    and the phase-2 operand fetches (ds_read_b64_tr_b16 piece addresses for K^T and dS^T, 16x16x32 MFMA k-slot order) reproduce
+    dQ^T = K^T dS^T exactly on integer data, and every access pattern is bank-conflict free under the MI355X lane-group rules.
+    The formulas in the tool are the kernel's; change both together."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_attn_bwd_fused.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "phase-2 values OK" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
