@@ -36,17 +36,26 @@ static constexpr int NC = 512;            // complex points
 #ifndef PA_MEL_FRAMES
 #define PA_MEL_FRAMES 16
 #endif
-static constexpr int FR_PER_WG = PA_MEL_FRAMES;   // frames per workgroup
+static constexpr int FR_DEFAULT = PA_MEL_FRAMES;  // frames per workgroup (template parameter FR_PER_WG of the kernel)
 static constexpr int MEL_WAVES = 4;
 static constexpr int XROW1 = 68;          // exchange-1 row stride (complex) : conflict-free reads
 static constexpr int XROW2 = 72;          // exchange-2 row stride (complex)
 static constexpr int WAVE_SCRATCH = 8 * XROW2 * 8;   // 4608 bytes
 
-struct cf { float x, y; };
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ cf cmul_negi(cf a) { return {a.y, -a.x}; }   // a * (-i)
+// complex numbers are 2-vectors: add / sub / scale are ONE packed instruction each (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32) --
+// written on a {float x, y} struct the same butterflies compile to 131 VALU per two 8-point DFTs + 7 twiddles (a third of them
+// v_mov to re-pair operands), written on vectors to 96 (round 5)
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf cswap(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cf cmul_negi(cf a) { cf s = cswap(a); s.y = -s.y; return s; }   // a * (-i) = {a.y, -a.x}
+__device__ __forceinline__ cf cmul(cf a, cf b) {           // {ax bx - ay by, ax by + ay bx} = a.xx * b + a.yy * {-by, bx}
+    const cf axx = {a.x, a.x}, ayy = {a.y, a.y};
+    cf t = cswap(b);
+    t.x = -t.x;
+    return axx * b + ayy * t;
+}
 
 // in-place 8-point DFT, natural order in and out:  X[p] = sum_a v[a] exp(-2 pi i a p / 8)
 __device__ __forceinline__ void dft8(cf (&v)[8]) {
@@ -58,9 +67,9 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     const cf t0 = cadd(s0, s2), t1 = csub(s0, s2), t2 = cadd(s1, s3), t3 = cmul_negi(csub(s1, s3));
     v[0] = cadd(t0, t2); v[4] = csub(t0, t2); v[2] = cadd(t1, t3); v[6] = csub(t1, t3);
     const cf e0 = d0;
-    const cf e1 = {(d1.x + d1.y) * R, (d1.y - d1.x) * R};      // d1 * (1 - i)/sqrt2
+    const cf e1 = (d1 + cmul_negi(d1)) * R;                    // d1 * (1 - i)/sqrt2 = {(x + y) R, (y - x) R}
     const cf e2 = cmul_negi(d2);
-    const cf e3 = {(d3.y - d3.x) * R, -(d3.x + d3.y) * R};     // d3 * (-1 - i)/sqrt2
+    const cf e3 = (cmul_negi(d3) - d3) * R;                    // d3 * (-1 - i)/sqrt2 = {(y - x) R, -(x + y) R}
     const cf u0 = cadd(e0, e2), u1 = csub(e0, e2), u2 = cadd(e1, e3), u3 = cmul_negi(csub(e1, e3));
     v[1] = cadd(u0, u2); v[5] = csub(u0, u2); v[3] = cadd(u1, u3); v[7] = csub(u1, u3);
 }
@@ -71,6 +80,7 @@ __device__ __forceinline__ cf tw1024(const float2* __restrict__ tw, int j) {
     return (j & 512) ? cf{-t.x, -t.y} : cf{t.x, t.y};
 }
 
+template <int FR_PER_WG>
 __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const float* __restrict__ wave, int L,
                                                             const float* __restrict__ window,
                                                             const float* __restrict__ bin_mel,
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const int n = 64 * a + lane;
-            v[a] = {sig[2 * n] * win[2 * a], sig[2 * n + 1] * win[2 * a + 1]};
+            v[a] = cf{sig[2 * n], sig[2 * n + 1]} * cf{win[2 * a], win[2 * a + 1]};
         }
         dft8(v);
 #pragma unroll
@@ -216,11 +226,15 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
             const int k = lane + 64 * s;
             const cf zk = v[s];
             const cf zc = scr[(NC - k) & (NC - 1)];            // Z[512-k] (Z[512] == Z[0])
-            const cf e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};         // (Z[k] + conj Z[N-k]) / 2
-            const cf o = {0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x)};        // (Z[k] - conj Z[N-k]) / (2i)
-            const cf xo = cmul(o, tw3[s]);
-            const cf X = cadd(e, xo);
-            pk[s] = X.x * X.x + X.y * X.y;
+            // X = (Z[k] + conj Z[N-k]) / 2 + W^k (Z[k] - conj Z[N-k]) / (2i): the two halves as packed sums of Z[k] and
+            // {zc.x, -zc.y}; the 1/2's are applied once, to the power (x 1/4)
+            cf zcc = zc;
+            zcc.y = -zcc.y;                                    // conj Z[N-k]
+            const cf e2 = zk + zcc;                            // 2 e
+            const cf o2 = cmul_negi(zk - zcc);                 // 2 o = (Z[k] - conj Z[N-k]) / i
+            const cf X2 = e2 + cmul(o2, tw3[s]);               // 2 X
+            const cf sq = X2 * X2;
+            pk[s] = 0.25f * (sq.x + sq.y);
         }
         // every bin feeds at most two triangles: store its two contributions, up[k] = P u (to triangle j_k) and
         // dn[k] = P (1 - u) (to triangle j_k - 1), so that the band sums below read one value per bin
@@ -273,17 +287,20 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     if (p->n_fft != NFFT || p->n_mels < 4 || p->n_mels > 128 || p->hop <= 0 || p->hop > NFFT) return PA_EUNSUPPORTED;
     if (L - 1 <= NFFT / 2) return PA_EUNSUPPORTED;          // reflect padding needs L-1 > n_fft/2 (torch.stft rule)
     if (p->n_frames != pa_mel_num_frames(L, p->hop)) return PA_EINVAL;
-    const int span = (FR_PER_WG - 1) * p->hop + NFFT;
+    // 16 frames per workgroup (64-byte output rows, three workgroups per CU).  Measured and not adopted (round 5,
+    // profiles/r05_mel_variants.txt): 8 frames per workgroup for grids that leave CUs without their three workgroups (ESC-50 at
+    // batch 12: 375 workgroups): 21.5-22.5 us against 20.6-21.3 -- the per-workgroup set-up is amortised over half the frames
+    const int fr = FR_DEFAULT;
+    const int span = (fr - 1) * p->hop + NFFT;
     const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH + 132 * 4 +
-                       std::max<size_t>((size_t)p->n_mels * (FR_PER_WG + 1) * 4, 2 * NC * 4);
+                       std::max<size_t>((size_t)p->n_mels * (fr + 1) * 4, 2 * NC * 4);
     if (lds > 160 * 1024) return PA_EUNSUPPORTED;
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)mel_frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024) == hipSuccess;
+        return hipFuncSetAttribute((const void*)mel_frontend_kernel<FR_DEFAULT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     }();
     (void)attr_set;
-    dim3 grid((unsigned)cdiv(p->n_frames, FR_PER_WG), (unsigned)B);
-    hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(MEL_WAVES * 64), lds, (hipStream_t)stream, wave, L, window, bin_mel,
+    dim3 grid((unsigned)cdiv(p->n_frames, fr), (unsigned)B);
+    hipLaunchKernelGGL(mel_frontend_kernel<FR_DEFAULT>, grid, dim3(MEL_WAVES * 64), lds, (hipStream_t)stream, wave, L, window, bin_mel,
                        (const float2*)twiddle, out, *p);
     return check_launch();
 }

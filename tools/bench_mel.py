@@ -15,7 +15,7 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     mel = passt_amd.AugmentMelSTFT(fmin_aug_range=10, fmax_aug_range=2000).to("cuda").eval()
 out = {"lib": os.environ.get("PASST_AMD_LIB", "default")}
-for B, L in ((64, 320000), (96, 160000)):
+for B, L in ((64, 320000), (96, 160000), (12, 160000)):
     wave = (torch.rand(B, L, device="cuda") * 2 - 1) * 0.1
     sec = timeit(lambda: mel(wave), 30)
     byts = 4.0 * (B * L + B * 128 * (1 + (L - 1) // 320))
