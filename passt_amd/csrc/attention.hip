@@ -856,8 +856,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 // all keys with v_mfma_f32_16x16x32_bf16, both operands fetched by transposed LDS reads (K^T from the resident K rows,
 // dS^T from T): no cross-wave reduction of partial sums, no atomics, deterministic.  T is double buffered, so phase 2 of
 // tile t overlaps phase 1 of tile t + 1 on the other wave of the SIMD.
-// Per (64 keys x 32 queries): 32 + 4 (x 0.5) MFMAs of 32x32x16 worth of matrix work instead of 56, one exp pass instead
-// of two, no delta hand-over launch; Q / dO / K / V are read from HBM once per head instead of 4 + 4 times.
+// Per (64 keys x 32 queries): 32 MFMAs of 32x32x16 + 16 of 16x16x32 (= 8 of the former in matrix time) instead of 56, one exp
+// pass instead of two, no delta hand-over launch; Q / dO / K / V are read from HBM once per head instead of 4 + 4 times.
 // LDS: K 64 KiB + T 2 x 32 KiB + Q/dO stages 2 x 8 KiB + per-query scalars 4 KiB = 148 KiB (one workgroup per CU, two
 // waves per SIMD, 256 registers each).  Index math of T and of the phase-2 operand fetches: tools/emulate_attn_bwd_fused.py
 // (values and bank conflicts under the MI355X lane-group rules, on the CPU).
