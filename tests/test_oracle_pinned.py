@@ -22,7 +22,7 @@ def _load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name + ".npz")))
 
 
-def _oracle_model_case(case):
+def _oracle_model_case(case, backward=True):
     cfg = case["cfg"]
     sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]), requires_grad=case["training"])
     x, y = G.model_inputs(case)
@@ -32,7 +32,8 @@ def _oracle_model_case(case):
     loss = None
     if case["training"]:
         loss = O.bce_loss(logits, torch.from_numpy(y))
-        loss.backward()
+        if backward:
+            loss.backward()
     return sd, logits, feat, loss
 
 
@@ -85,10 +86,15 @@ def test_config2_batch64_oracle_vs_golden(golden_dir, name):
     produced at that size (random input; model_speed_test's constant batch)."""
     case = G.B64_CASES[name]
     gold = _load(golden_dir, name)
-    sd, logits, feat, loss = _oracle_model_case(case)
+    # (the constant-batch case is pinned on its forward and loss only: its backward is the same code on other numbers, and the
+    # random case below pins every gradient -- keeps the CPU suite at a few minutes)
+    with_grads = case.get("inputs") != "ones"
+    sd, logits, feat, loss = _oracle_model_case(case, backward=with_grads)
     np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], atol=5e-5, rtol=2e-4)
     np.testing.assert_allclose(feat.detach().numpy(), gold["features"], atol=5e-5, rtol=2e-4)
     assert abs(loss.item() - float(gold["loss"])) < 1e-6
+    if not with_grads:
+        return
     for k, p in sd.items():
         if "gradnone." + k in gold:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
