@@ -87,6 +87,13 @@ def algorithmic_gflop_per_clip(N=474, D=768, depth=12, kept_patches=472):
     return 3 * fwd / 1e9
 
 
+def skipped_tail_gflop_per_clip(N=474, D=768):
+    """FLOPs of the reference algorithm the prefix-only tail does NOT execute: the last block's proj / fc1 / fc2
+    on the N - 2 non-prefix rows (18 D^2 per row forward) and its attention for the N - 2 non-prefix queries (4 N D per query),
+    forward + backward = 3 x forward."""
+    return 3 * (18.0 * (N - 2) * D * D + 4.0 * (N - 2) * N * D) / 1e9
+
+
 def modelled_scaling(ms_step_1gpu, bucket_bytes, link_gbps=153.0, links=7, bus_eff=0.35):
     """MODELLED (not measured) weak-scaling curve for N = 2, 4, 8 GPUs of one node from the measured single-GPU step and
     the measured per-bucket wire bytes: ring all-reduce of S bytes moves 2 (N-1)/N S per GPU; xGMI is point-to-point,
@@ -726,6 +733,9 @@ def run(args):
                        "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
             "algorithmic_gflop_per_clip": round(gflop_clip, 2),
             "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
+            # the same on the FLOPs actually executed: the prefix-only tail skips part of the last block (exactly)
+            "mfma_frac_end_to_end_executed": round(value / world * (gflop_clip - skipped_tail_gflop_per_clip(cfgd["tokens"], Dm)) / 1e3
+                                                   / BF16_MFMA_PEAK_TFLOPS, 4),
             "loss": round(loss_v, 6),
         }
         if prof:
