@@ -868,6 +868,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #define PA_FUSED_ABL 0
 #endif
 
+
 static constexpr int FK = 512;                                   // key rows of the resident K tile (N <= FK)
 static constexpr int FT_PLANE = FK * 32;                         // one 16-query plane of T: FK keys x 16 queries x 2 B
 static constexpr int F_OFF_T = FK * 128;
@@ -1157,22 +1158,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *(u32x4*)(sK + (N + (i >> 3)) * 128 + (i & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    auto tile = [&](auto buf_tag, int t) __attribute__((always_inline)) {
-        if (t + 1 < nt) stage(t + 1);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using NCH = std::integral_constant<int, 4>;      // phase 2 walks the whole K tile (16 steps of 32 keys) whatever N is
+    auto phase1 = [&](auto buf_tag, int t) __attribute__((always_inline)) {
         if (kbase0 < N) block(std::integral_constant<int, 0>{}, buf_tag, t);
         if (kbase0 + 32 < N) block(std::integral_constant<int, 1>{}, buf_tag, t);
+    };
+    auto sync = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(PA_FUSED_ABL & 16)) __syncthreads();
-        // phase 2 walks the whole K tile (16 steps of 32 keys) whatever N is: straight-line code, one instantiation; at the
-        // headline 474 tokens that is one step more than the 15 that hold keys
-        if (!(PA_FUSED_ABL & 1)) phase2(buf_tag, std::integral_constant<int, 4>{}, t);
+    };
+    // (Measured and dropped, profiles/r05_attention_single_pass.txt: the two waves of a SIMD running phase 2 / phase 1 of an
+    // inter-barrier interval in OPPOSITE orders -- two loop nests chosen once per wave.  The second nest costs the allocator four
+    // spilled registers per tile, and a reload inside the tile loop waits for the Q / dO prefetch in flight: 270-277 us against 183.)
+    auto tile = [&](auto buf_tag, int t) __attribute__((always_inline)) {
+        if (t + 1 < nt) stage(t + 1);
+        phase1(buf_tag, t);
+        sync();
+        if (!(PA_FUSED_ABL & 1)) phase2(buf_tag, NCH{}, t);
     };
     int t = 0;
     for (; t + 1 < nt; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        tile(std::integral_constant<int, 1>{}, t + 1);
+        tile(B0{}, t);
+        tile(B1{}, t + 1);
     }
-    if (t < nt) tile(std::integral_constant<int, 0>{}, t);
+    if (t < nt) tile(B0{}, t);
     T* out = dqkv + (int64_t)b * N * lddqkv + h * HD;
     int ln = lane;
     asm volatile("" : "+v"(ln));                                 // the row pointers are formed here, not kept in registers across the tile loop
