@@ -215,3 +215,19 @@ def test_bench_sweep_dry_run():
     assert two["rccl_nranks"] == 2 and two["allreduce_bus_GBps_idle"] == two["allreduce_measured"]["idle"]["bus_GBps_total"] > 0
     assert list(two)[:16].index("allreduce_bus_GBps_idle") < list(two).index("config")
     assert two["scaling_model"]["bus_efficiency"] == 0.35 and "ASSUMED" in two["scaling_model"]["inputs"]
+
+
+def test_bench_speedtest_cli():
+    """`python bench.py --speedtest` (the reference's model_speed_test flow): one JSON line per batch size with the
+    dynamo / GradScaler evidence in it."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--speedtest", "--batch", "4", "--steps", "3", "--warmup", "2"],
+                       env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["unit"] == "specs/s" and d["value"] > 0 and d["config"]["per_gpu_batch"] == 4 and d["config"]["compiled"] is True
+    assert d["grad_scale_after"] == 65536.0 and d["dynamo"]["graphs_captured"] == 0 and d["logits_dtype"] == "torch.float32"
+    assert d["dynamo"]["frames_total"] == d["dynamo"]["frames_after_warmup"] <= 1
