@@ -30,10 +30,11 @@ from . import ops
 def my_mixup(size, alpha, device=None):
     """helpers/mixup.py:5-12.  ``device``: where the results go; None = the current HIP device when one is visible (one process
     per GPU: the device Lightning / the caller selected), else the CPU -- then this IS the reference function."""
-    rn_indices = torch.randperm(size)                                               # :6
-    lambd = np.random.beta(alpha, alpha, size).astype(np.float32)                   # :7
-    lambd = np.concatenate([lambd[:, None], 1 - lambd[:, None]], 1).max(1)          # :8
-    lam = torch.from_numpy(lambd)                                                   # :9  (torch.FloatTensor(lambd))
+    # the reference's two draws, in its order: torch's CPU generator for the permutation, numpy's global generator for the Beta
+    # samples (helpers/mixup.py:6-7); lam = max(l, 1 - l) in float32 (:8: concatenate([l, 1 - l]).max(1) is that element-wise max)
+    rn_indices = torch.randperm(size)
+    beta = np.random.beta(alpha, alpha, size).astype(np.float32)
+    lam = torch.from_numpy(np.maximum(beta, np.float32(1.0) - beta))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     device = torch.device(device)
