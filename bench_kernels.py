@@ -109,7 +109,9 @@ def main():
     add(f"attention fwd B{B} H{H} N{N}", sec, flops=4.0 * N * N * 64 * B * H)
     do = rnd(M, D)
     sec = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED), args.iters)
-    add(f"attention bwd (delta + dkdv + dq) B{B} H{H} N{N}", sec, flops=10.0 * N * N * 64 * B * H)
+    add(f"attention bwd (library's choice: single pass for B*H >= 512, N <= 512) B{B} H{H} N{N}", sec, flops=10.0 * N * N * 64 * B * H)
+    sec = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, H, N, 0.125, flags=ops.ATTN_Q_PRESCALED | ops.ATTN_BWD_TWO_PASS), args.iters)
+    add(f"attention bwd, two kernels (dq + dkdv) B{B} H{H} N{N}", sec, flops=10.0 * N * N * 64 * B * H)
     # ---- layer norm ----
     g, b_ = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     y, mean, rstd = ops.layernorm_fwd(xf, g, b_, 1e-6, PA_BF16)
