@@ -38,9 +38,16 @@ static constexpr int NC = 512;            // complex points
 #endif
 static constexpr int FR_DEFAULT = PA_MEL_FRAMES;  // frames per workgroup (template parameter FR_PER_WG of the kernel)
 static constexpr int MEL_WAVES = 4;
+#ifndef PA_MEL_ABL
+#define PA_MEL_ABL 0
+#endif
+#ifndef PA_MEL_LEAN
+#define PA_MEL_LEAN 3                     // how many of the untangle twiddles use the one-copy product (register budget: 168)
+#endif
 static constexpr int XROW1 = 68;          // exchange-1 row stride (complex) : conflict-free reads
 static constexpr int XROW2 = 72;          // exchange-2 row stride (complex)
 static constexpr int WAVE_SCRATCH = 8 * XROW2 * 8;   // 4608 bytes
+static constexpr int SLOT_DUMMY = 130;               // band-stage slots: [0, 128] real, 129 pad, 130 + lane private dummies
 
 // complex numbers are 2-vectors: add / sub / scale are ONE packed instruction each (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32) --
 // written on a {float x, y} struct the same butterflies compile to 131 VALU per two 8-point DFTs + 7 twiddles (a third of them
@@ -49,12 +56,27 @@ typedef float cf __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 __device__ __forceinline__ cf cswap(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cf bcast(cf a, int h) { return h ? __builtin_shufflevector(a, a, 1, 1) : __builtin_shufflevector(a, a, 0, 0); }
 __device__ __forceinline__ cf cmul_negi(cf a) { cf s = cswap(a); s.y = -s.y; return s; }   // a * (-i) = {a.y, -a.x}
 __device__ __forceinline__ cf cmul(cf a, cf b) {           // {ax bx - ay by, ax by + ay bx} = a.xx * b + a.yy * {-by, bx}
     const cf axx = {a.x, a.x}, ayy = {a.y, a.y};
     cf t = cswap(b);
     t.x = -t.x;
     return axx * b + ayy * t;
+}
+
+// a -+ i b and the conjugate sums as ONE packed FMA each: the swap of b's halves is an op_sel modifier, the signs are a constant
+// pair (exact: the multiplier is +-1).  Written as add(a, negi(b)) the compiler materialises {b.y, -b.x} with v_xor + v_mov first.
+__device__ __forceinline__ cf addni(cf a, cf b) { return __builtin_elementwise_fma(cswap(b), cf{1.f, -1.f}, a); }   // a + (-i) b
+__device__ __forceinline__ cf subni(cf a, cf b) { return __builtin_elementwise_fma(cswap(b), cf{-1.f, 1.f}, a); }   // a - (-i) b
+__device__ __forceinline__ cf addcj(cf a, cf b) { return __builtin_elementwise_fma(b, cf{1.f, -1.f}, a); }          // a + conj b
+__device__ __forceinline__ cf subcj(cf a, cf b) { return __builtin_elementwise_fma(b, cf{-1.f, 1.f}, a); }          // a - conj b
+
+// the same product in three instructions but from ONE copy of b: cmul keeps {b.x, b.y} and {-b.y, b.x} of a loop-invariant
+// twiddle in registers (two pairs); used for a few twiddles so that the kernel stays at three waves per SIMD
+__device__ __forceinline__ cf cmul_lean(cf a, cf b) {
+    const cf axx = {a.x, a.x}, ayy = {a.y, a.y};
+    return __builtin_elementwise_fma(cswap(ayy * b), cf{-1.f, 1.f}, axx * b);    // {ax bx - ay by, ax by + ay bx}
 }
 
 // in-place 8-point DFT, natural order in and out:  X[p] = sum_a v[a] exp(-2 pi i a p / 8)
@@ -64,14 +86,28 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     const cf s1 = cadd(v[1], v[5]), d1 = csub(v[1], v[5]);
     const cf s2 = cadd(v[2], v[6]), d2 = csub(v[2], v[6]);
     const cf s3 = cadd(v[3], v[7]), d3 = csub(v[3], v[7]);
-    const cf t0 = cadd(s0, s2), t1 = csub(s0, s2), t2 = cadd(s1, s3), t3 = cmul_negi(csub(s1, s3));
-    v[0] = cadd(t0, t2); v[4] = csub(t0, t2); v[2] = cadd(t1, t3); v[6] = csub(t1, t3);
-    const cf e0 = d0;
-    const cf e1 = (d1 + cmul_negi(d1)) * R;                    // d1 * (1 - i)/sqrt2 = {(x + y) R, (y - x) R}
-    const cf e2 = cmul_negi(d2);
-    const cf e3 = (cmul_negi(d3) - d3) * R;                    // d3 * (-1 - i)/sqrt2 = {(y - x) R, -(x + y) R}
-    const cf u0 = cadd(e0, e2), u1 = csub(e0, e2), u2 = cadd(e1, e3), u3 = cmul_negi(csub(e1, e3));
-    v[1] = cadd(u0, u2); v[5] = csub(u0, u2); v[3] = cadd(u1, u3); v[7] = csub(u1, u3);
+    const cf t0 = cadd(s0, s2), t1 = csub(s0, s2), t2 = cadd(s1, s3), t3 = csub(s1, s3);      // t3 enters times -i
+    v[0] = cadd(t0, t2); v[4] = csub(t0, t2); v[2] = addni(t1, t3); v[6] = subni(t1, t3);
+    const cf e1 = addni(d1, d1) * R;                           // d1 * (1 - i)/sqrt2 = {(x + y) R, (y - x) R}
+    const cf e3 = subni(d3, d3) * -R;                          // d3 * (-1 - i)/sqrt2 = {(y - x) R, -(x + y) R}
+    const cf u0 = addni(d0, d2), u1 = subni(d0, d2), u2 = cadd(e1, e3), u3 = csub(e1, e3);    // u3 enters times -i
+    v[1] = cadd(u0, u2); v[5] = csub(u0, u2); v[3] = addni(u1, u3); v[7] = subni(u1, u3);
+}
+
+// v_mov_dpp with old = 0 and bound_ctrl: lanes without a source (or outside row_mask) read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, true); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ cf dpp_c(cf v) {
+    const float x = v[0], y = v[1];       // (__builtin_bit_cast on a vector ELEMENT reads element 0 whichever is named)
+    return cf{__int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(x))), __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(y)))};
+}
+
+// one step of the segmented scan: every lane fetches (DPP is convergent: all lanes execute it), the predicate only gates the add
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ cf seg_step(cf t, bool take) {
+    const cf d = dpp_c<CTRL, ROW_MASK>(t);
+    return t + (take ? d : cf{0.f, 0.f});
 }
 
 // exp(-2 pi i j / 1024) for j in [0, 1024) from the half table
@@ -90,9 +126,8 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
     const int span = (FR_PER_WG - 1) * p.hop + NFFT;
     float* sSig = (float*)smem;                                        // [span] pre-emphasised, reflect-padded
     char* sScr = smem + ((span * 4 + 15) & ~15);                       // [8 waves][WAVE_SCRATCH]
-    int* sS = (int*)(sScr + MEL_WAVES * WAVE_SCRATCH);                 // [n_mels + 3] first bin with j >= b
-    float* sOut = (float*)(sS + 132);                                  // [n_mels][33]
-    // the two per-bin tables are only needed until every lane holds its 8 weights and sS is built: they live in the
+    float* sOut = (float*)(sScr + MEL_WAVES * WAVE_SCRATCH);           // [n_mels][FR_PER_WG + 1]
+    // the two per-bin tables are only needed until every lane holds its band-stage constants: they live in the
     // (not yet written) output tile, which keeps the workgroup under 80 KiB = two workgroups per CU
     float* sU = sOut;                                                  // [512] up-slope weight of bin k
     int* sJ = (int*)(sU + NC);                                         // [512] triangle index of bin k
@@ -100,13 +135,40 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
+#ifdef PA_MEL_PROBE      // probe build (tools/probe_mel.py): s_memrealtime stamps (100 MHz) of the phases of every wave, left in the output tile
+    uint32_t stamp[6];       // few and 32-bit: the kernel is at its SGPR / VGPR budget, a bigger probe would change its occupancy
+#define MEL_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MEL_STAMP(i) do {} while (0)
+#endif
+    MEL_STAMP(0);
     const int f0 = blockIdx.x * FR_PER_WG;
     const int T = p.n_frames;
     const int Ly = L - 1;
     const float* x = wave + (int64_t)b * L;
 
-    // ---- stage the signal span: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2 ----
+    // ---- per-lane constants: requested first, so that the (L2-resident) tables arrive while the span is staged ----
+    cf tw1[8], tw2[8], tw3[8];
+    float win[16];
+    {
+        const int m = lane;                  // stage-1 role: m
+        const int c = lane >> 3;             // stage-2 role: (c, p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            tw1[q] = tw1024(twiddle, 2 * m * q);          // W512^(m q)
+            tw2[q] = tw1024(twiddle, 16 * c * q);         // W64^(c q)
+            tw3[q] = tw1024(twiddle, lane + 64 * q);      // W1024^k, k = lane + 64 q
+            win[2 * q] = window[2 * (64 * q + m)];
+            win[2 * q + 1] = window[2 * (64 * q + m) + 1];
+        }
+    }
+
+    // ---- stage the signal span: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2.  (Measured and not kept, round 5:
+    // geometry + band-stage constants worked out while the span loads are in flight, the span stored last -- the prologue
+    // shrinks by 0.8 us, the frames of the co-resident workgroups slow down by 0.4, the launch stays at 92 us.) ----
     constexpr int NT = MEL_WAVES * 64;
+    static_assert(NC == 2 * NT, "two bins per thread");
+    const float bm0 = bin_mel[tid], bm1 = bin_mel[tid + NT];   // requested here, used behind the span
     const int i0 = f0 * p.hop - NFFT / 2;                    // sample index of sSig[0]
     if (i0 >= 0 && i0 + span + 4 <= Ly && ((i0 | L) & 3) == 0 && (span & 3) == 0 && span <= 12 * 4 * NT) {
         // interior tile (no reflection, 16-byte aligned): one 16-byte load + the next sample per 4 outputs, every
@@ -141,46 +203,56 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
             sSig[j] = x[i + 1] - p.preemph * x[i];
         }
     }
+    MEL_STAMP(1);
     // ---- filterbank geometry for this call's (fmin, fmax): bin k -> triangle j_k, weight u_k ----
-    for (int k = tid; k < NC; k += NT) {
-        const float t = (bin_mel[k] - p.mel_low) * p.inv_mel_delta;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float t = ((h ? bm1 : bm0) - p.mel_low) * p.inv_mel_delta;
         const float fl = floorf(t);
-        sJ[k] = (int)fmaxf(fminf(fl, 100000.f), -1.f);
-        sU[k] = t - fl;
+        sJ[tid + h * NT] = (int)fmaxf(fminf(fl, 100000.f), -1.f);
+        sU[tid + h * NT] = t - fl;
     }
     __syncthreads();
-    if (tid <= p.n_mels + 2) {       // sS[b] = #bins with j_k < b  (j_k is non-decreasing in k)
-        int lo = 0, hi = NC;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sJ[mid] < tid) lo = mid + 1; else hi = mid;
-        }
-        sS[tid] = lo;
-    }
-    __syncthreads();
-
-    // ---- per-lane constants ----
-    cf tw1[8], tw2[8], tw3[8];
-    float win[16];
-    {
-        const int m = lane;                  // stage-1 role: m
-        const int c = lane >> 3;             // stage-2 role: (c, p)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            tw1[q] = tw1024(twiddle, 2 * m * q);          // W512^(m q)
-            tw2[q] = tw1024(twiddle, 16 * c * q);         // W64^(c q)
-            tw3[q] = tw1024(twiddle, lane + 64 * q);      // W1024^k, k = lane + 64 q
-            win[2 * q] = window[2 * (64 * q + m)];
-            win[2 * q + 1] = window[2 * (64 * q + m) + 1];
-        }
-    }
     cf* scr = (cf*)(sScr + wv * WAVE_SCRATCH);
-    float* up = (float*)scr;                 // per-bin contributions overlay the scratch (2 x 512 floats of its 1152)
-    float* dn = up + NC;
-    float bu[8];                             // up-slope weight of this lane's 8 bins k = lane + 64 s
+    // ---- band-stage constants (tools/emulate_mel_bands.py is this stage on the CPU).  Lane L owns the 8 consecutive bins
+    // [8L, 8L + 8); bins with the same triangle index j form a segment whose two sums (up-slope contributions -> band j,
+    // down-slope contributions -> band j - 1) are wanted.  keep[i]: bin i continues the segment of bin i - 1;  sa[i]: the slot the
+    // segment that ends in front of bin i is flushed to (a private dummy slot when none ends there / it lies outside the bank);
+    // sw[s]: the predicate of step s of the wave-wide segmented scan over the lanes' open tails -- geometry only, not data ----
+    float* pex = (float*)scr;                                // [512] power spectrum, re-read as 8 consecutive bins per lane
+    cf* slot = (cf*)((char*)scr + NC * 4);                   // [n_mels + 1] {U_j, D_j}, one pad, 64 dummies: 1552 B of the 4608
+    float un[8];
+    cf keep[4];                                              // 1.f / 0.f per bin, two per register pair: the recurrence gates with
+    uint32_t sa[4];                                          // ONE packed FMA per bin (the broadcast of a half is an op_sel modifier);
+    int j_last;                                              // slot indices two per register (16 bits each)
+    bool sw[6];
+    {
+        const int dummy = SLOT_DUMMY + lane;
+        int jprev = lane == 0 ? -1 : sJ[8 * lane - 1];
+        int heads = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bu[q] = sU[lane + 64 * q];
+        for (int i = 0; i < 8; ++i) {
+            const int k = 8 * lane + i;
+            const int jk = sJ[k];
+            const bool boundary = k > 0 && jk != jprev;
+            keep[i >> 1][i & 1] = boundary ? 0.f : 1.f;
+            heads |= boundary;
+            const uint32_t a = (boundary && jprev >= 0 && jprev <= p.n_mels) ? jprev : dummy;
+            sa[i >> 1] = (i & 1) ? (sa[i >> 1] | (a << 16)) : a;
+            un[i] = 0.25f * sU[k];
+            jprev = jk;
+        }
+        j_last = __builtin_amdgcn_readlane(jprev, 63);        // the segment that is still open behind bin 511 (wave-uniform)
+        int f = heads;                                       // this lane's tail starts a new segment
+        sw[0] = f == 0; f |= dpp_i<0x111, 0xF>(f);           // row_shr:1
+        sw[1] = f == 0; f |= dpp_i<0x112, 0xF>(f);           // row_shr:2
+        sw[2] = f == 0; f |= dpp_i<0x114, 0xF>(f);           // row_shr:4
+        sw[3] = f == 0; f |= dpp_i<0x118, 0xF>(f);           // row_shr:8
+        sw[4] = f == 0; f |= dpp_i<0x142, 0xA>(f);           // row_bcast15 into rows 1, 3
+        sw[5] = f == 0;                                      // row_bcast31 into rows 2, 3
+    }
     __syncthreads();                         // sU / sJ are dead from here on: their LDS is the output tile
+    MEL_STAMP(2);
 
     for (int fi = 0; fi < FR_PER_WG / MEL_WAVES; ++fi) {
         const int fl = wv * (FR_PER_WG / MEL_WAVES) + fi;
@@ -217,6 +289,15 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
             for (int c = 0; c < 8; ++c) v[c] = scr[r * XROW2 + c * 8 + pp];
         }
         dft8(v);                              // over c -> s ; lane' holds Z[lane' + 64 s]
+#if PA_MEL_ABL >= 2      // ablation builds (probe only): 2 = no untangle, no band stage; 1 = no band stage
+        {
+            cf a = v[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) a += v[s];
+            sOut[lane * (FR_PER_WG + 1) + fl] = a.x;
+            sOut[(lane + 64) * (FR_PER_WG + 1) + fl] = a.y;
+        }
+#else
         // untangle the packed real FFT: needs Z[k] and Z[512-k]
 #pragma unroll
         for (int s = 0; s < 8; ++s) scr[lane + 64 * s] = v[s];
@@ -226,43 +307,73 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
             const int k = lane + 64 * s;
             const cf zk = v[s];
             const cf zc = scr[(NC - k) & (NC - 1)];            // Z[512-k] (Z[512] == Z[0])
-            // X = (Z[k] + conj Z[N-k]) / 2 + W^k (Z[k] - conj Z[N-k]) / (2i): the two halves as packed sums of Z[k] and
-            // {zc.x, -zc.y}; the 1/2's are applied once, to the power (x 1/4)
-            cf zcc = zc;
-            zcc.y = -zcc.y;                                    // conj Z[N-k]
-            const cf e2 = zk + zcc;                            // 2 e
-            const cf o2 = cmul_negi(zk - zcc);                 // 2 o = (Z[k] - conj Z[N-k]) / i
-            const cf X2 = e2 + cmul(o2, tw3[s]);               // 2 X
+            // X = (Z[k] + conj Z[N-k]) / 2 + W^k (Z[k] - conj Z[N-k]) / (2i); the 1/2's are applied once, to the power (x 1/4),
+            // and that factor lives in the band weights (un = u / 4: exact)
+            const cf e2 = addcj(zk, zc);                       // 2 e
+            const cf o2 = cmul_negi(subcj(zk, zc));            // 2 o = (Z[k] - conj Z[N-k]) / i
+            const cf X2 = e2 + (s < PA_MEL_LEAN ? cmul_lean(o2, tw3[s]) : cmul(o2, tw3[s]));               // 2 X
             const cf sq = X2 * X2;
-            pk[s] = 0.25f * (sq.x + sq.y);
+            pk[s] = sq.x + sq.y;                               // 4 |X|^2
         }
-        // every bin feeds at most two triangles: store its two contributions, up[k] = P u (to triangle j_k) and
-        // dn[k] = P (1 - u) (to triangle j_k - 1), so that the band sums below read one value per bin
-        // (the Nyquist bin has no column in the kaldi bank: models/preprocess.py:73-74 pads a zero one)
+#if PA_MEL_ABL == 1
+        {
+            float a = pk[0];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {                             // all reads of scr are issued above
-            up[lane + 64 * s] = pk[s] * bu[s];
-            dn[lane + 64 * s] = pk[s] - pk[s] * bu[s];
+            for (int s = 1; s < 8; ++s) a += pk[s];
+            sOut[lane * (FR_PER_WG + 1) + fl] = a;
+            sOut[(lane + 64) * (FR_PER_WG + 1) + fl] = a * un[0] * keep[0].x * (float)sa[0];
         }
-        // sparse mel bands: this lane owns bands `lane` and `n_mels-1-lane` (one narrow + one wide): bins [k0, k1) on
-        // their up-slope, [k1, k2) on their down-slope; four independent partial sums keep four LDS reads in flight
+#else
+        // ---- sparse mel bands.  Every bin feeds at most two triangles: P u to triangle j_k, P (1 - u) to triangle j_k - 1.
+        // The power spectrum changes owner (lane + 64 s -> 8 consecutive bins per lane), every lane runs the segment
+        // recurrence acc = (keep ? acc : 0) + {P u, P - P u} over its bins -- once from zero (its open tail), then, after ONE
+        // segmented scan of the tails across the wave has produced what the lanes in front of it left open, again from that
+        // carry, dropping acc into the slot of every segment that ends.  No data-dependent loop, no LDS round trip per bin
+        // (round 5: the lane-per-band loops it replaces were half of the frame time: 26 dependent LDS round trips, probe
+        // profiles/r05_mel_probe.txt). ----
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pex[lane + 64 * s] = pk[s];   // all reads of scr are issued above
+        const f32x4 pa = *(const f32x4*)(pex + 8 * lane), pb = *(const f32x4*)(pex + 8 * lane + 4);
+        slot[lane] = cf{0.f, 0.f};
+        slot[lane + 64] = cf{0.f, 0.f};
+        if (lane < 2) slot[128 + lane] = cf{0.f, 0.f};
+        cf val[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float pw = i < 4 ? pa[i & 3] : pb[i & 3];
+            const float u = pw * un[i];                         // pw = 4 P, un = u / 4
+            val[i] = cf{u, __builtin_fmaf(pw, 0.25f, -u)};
+        }
+        cf acc = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_elementwise_fma(acc, bcast(keep[i >> 1], i & 1), val[i]);
+        cf t = acc;                                              // inclusive segmented scan of the tails
+        t = seg_step<0x111, 0xF>(t, sw[0]);
+        t = seg_step<0x112, 0xF>(t, sw[1]);
+        t = seg_step<0x114, 0xF>(t, sw[2]);
+        t = seg_step<0x118, 0xF>(t, sw[3]);
+        t = seg_step<0x142, 0xA>(t, sw[4]);
+        t = seg_step<0x143, 0xC>(t, sw[5]);
+        acc = dpp_c<0x138, 0xF>(t);                              // wave_shr:1: what the lanes in front left open
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            slot[(i & 1) ? (sa[i >> 1] >> 16) : (sa[i >> 1] & 0xFFFFu)] = acc;
+            acc = __builtin_elementwise_fma(acc, bcast(keep[i >> 1], i & 1), val[i]);
+        }
+        if (lane == 63 && j_last >= 0 && j_last <= p.n_mels) slot[j_last] = acc;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int band = h == 0 ? lane : p.n_mels - 1 - lane;
-            // h == 0 covers bands 0..63; h == 1 covers the remaining 64..n_mels-1 in reverse
-            const bool mine = h == 0 ? band < p.n_mels : band >= 64;
-            if (!mine) continue;
-            const int k0 = sS[band], k1 = sS[band + 1], k2 = sS[band + 2];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int k = k0;
-            for (; k + 3 < k1; k += 4) { a0 += up[k]; a1 += up[k + 1]; a2 += up[k + 2]; a3 += up[k + 3]; }
-            for (; k < k1; ++k) a0 += up[k];
-            for (; k + 3 < k2; k += 4) { a0 += dn[k]; a1 += dn[k + 1]; a2 += dn[k + 2]; a3 += dn[k + 3]; }
-            for (; k < k2; ++k) a1 += dn[k];
-            sOut[band * (FR_PER_WG + 1) + fl] = (a0 + a1) + (a2 + a3);
+            const int band = lane + 64 * h;
+            if (band < p.n_mels) sOut[band * (FR_PER_WG + 1) + fl] = slot[band].x + slot[band + 1].y;
         }
+#endif
+#endif
+#ifdef PA_MEL_PROBE
+        if (fi == 3) MEL_STAMP(3);
+#endif
     }
     __syncthreads();
+    MEL_STAMP(4);
     // ---- epilogue: log, SpecAugment masks, affine; rows of 32 frames = 128 contiguous bytes ----
     for (int idx = tid; idx < p.n_mels * FR_PER_WG; idx += NT) {
         const int mel = idx / FR_PER_WG, fl = idx % FR_PER_WG;
@@ -273,6 +384,15 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         if (masked) v = 0.f;
         out[((int64_t)b * p.n_mels + mel) * T + t] = (v + p.out_add) * p.out_scale;
     }
+#ifdef PA_MEL_PROBE
+    MEL_STAMP(5);
+    __syncthreads();
+    if (lane == 0) {
+        float* o = out + ((int64_t)b * p.n_mels + wv * 16) * T + f0;
+        o[0] = (float)(stamp[0] & 0xFFFFFFu);                 // absolute start, 10 ns units, 24 bits
+        for (int i = 1; i < 6; ++i) o[(int64_t)i * T] = (float)(stamp[i] - stamp[0]);
+    }
+#endif
 }
 
 }  // namespace pa
@@ -292,7 +412,7 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     // batch 12: 375 workgroups): 21.5-22.5 us against 20.6-21.3 -- the per-workgroup set-up is amortised over half the frames
     const int fr = FR_DEFAULT;
     const int span = (fr - 1) * p->hop + NFFT;
-    const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH + 132 * 4 +
+    const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH +
                        std::max<size_t>((size_t)p->n_mels * (fr + 1) * 4, 2 * NC * 4);
     if (lds > 160 * 1024) return PA_EUNSUPPORTED;
     static bool attr_set = [] {

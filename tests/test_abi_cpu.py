@@ -311,3 +311,13 @@ def test_single_pass_attention_backward_index_math_on_the_cpu():
     The formulas in the tool are the kernel's; change both together."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_attn_bwd_fused.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "phase-2 values OK" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+
+
+def test_front_end_band_stage_emulated_on_the_cpu():
+    """mel.hip's band stage (lane-local segment recurrence + one DPP segmented scan across the wave) statement by statement in
+    numpy against the definition of the sparse filterbank product, over random geometries"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emulate_mel_bands", os.path.join(ROOT, "tools", "emulate_mel_bands.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.self_check(trials=40, seed=3) < 5e-6

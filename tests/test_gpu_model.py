@@ -190,6 +190,25 @@ def test_frontend_vs_oracle_random_augment():
     assert whole > 0        # at least one draw masked the entire clip (impossible with a clamped parameter)
 
 
+@pytest.mark.parametrize("kw", [dict(n_mels=128), dict(n_mels=64), dict(n_mels=40, fmin=300.0, fmax=8000), dict(n_mels=5),
+                                dict(n_mels=4, fmin=2000.0, fmax=4000), dict(n_mels=128, fmin=50.0, fmax=1200),
+                                dict(n_mels=23, fmax=16000)])
+def test_frontend_band_stage_on_other_filterbanks(kw):
+    """the band sums come out of a geometry-driven segmented scan (tools/emulate_mel_bands.py): triangles that span many lanes'
+    bins (few mel bands), triangles narrower than a bin (128 bands under 1.2 kHz: empty filters), bins below fmin / above fmax"""
+    kw = dict(dict(fmin_aug_range=1, fmax_aug_range=1), **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mel = passt_amd.AugmentMelSTFT(**kw).to(DEV).eval()
+    wave_np = G.frontend_inputs(dict(B=2, L=35000, seed=91))
+    ref = O.mel_frontend(torch.from_numpy(wave_np), training=False, **kw).numpy()
+    got = mel(torch.from_numpy(wave_np).to(DEV)).cpu().numpy()
+    assert got.shape == ref.shape == (2, kw["n_mels"], 110)
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - ref).max()) < 1e-3
+    assert torch.equal(mel(torch.from_numpy(wave_np).to(DEV)).cpu(), torch.from_numpy(got))        # deterministic
+
+
 def test_module_contract():
     """state_dict schema, parameter order, deepcopy, tuple output."""
     import copy
