@@ -149,6 +149,36 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         if (lane == 0) y[(int64_t)b * C + c] = s + bc;
     }
 }
+// the same for D = 64 NV (the model widths): no predicates, the class row in registers, four batch rows in flight per wave
+// (round 5: one row at a time is 16 dependent L2 round trips per wave at B = 64; same summation order, bit-identical)
+template <int NV>
+__global__ __launch_bounds__(256) void linear_fwd_rows4_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int C) {
+    constexpr int D = 64 * NV;
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float bc = bias ? bias[c] : 0.f;
+    float wr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) wr[i] = W[(int64_t)c * D + lane + 64 * i];
+    auto dot = [&](int b) {
+        const float* xr = x + (int64_t)min(b, B - 1) * D + lane;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i + 1 < NV; i += 2) { s0 += xr[64 * i] * wr[i]; s1 += xr[64 * (i + 1)] * wr[i + 1]; }
+        if (NV & 1) s0 += xr[64 * (NV - 1)] * wr[NV - 1];
+        return s0 + s1;
+    };
+    for (int b = wave; b < B; b += 16) {
+        const float p0 = dot(b), p1 = dot(b + 4), p2 = dot(b + 8), p3 = dot(b + 12);     // rows past B repeat row B - 1, not stored
+        const float r0 = wave_sum(p0), r1 = wave_sum(p1), r2 = wave_sum(p2), r3 = wave_sum(p3);
+        if (lane == 0) {
+            y[(int64_t)b * C + c] = r0 + bc;
+            if (b + 4 < B) y[(int64_t)(b + 4) * C + c] = r1 + bc;
+            if (b + 8 < B) y[(int64_t)(b + 8) * C + c] = r2 + bc;
+            if (b + 12 < B) y[(int64_t)(b + 12) * C + c] = r3 + bc;
+        }
+    }
+}
 // dx[b][d] = sum_c dy[b][c] W[c][d]: workgroup = (64 columns d, one row b); the 4 waves split the classes (W rows read
 // as 256-byte runs, dy[b][c] is wave-uniform), partial sums meet in LDS
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
@@ -260,7 +290,9 @@ extern "C" int pa_head_pre_bwd(const float* dhn, const float* dfeat, const float
 
 extern "C" int pa_linear_f32_fwd(const float* x, const float* W, const float* b, float* y, int B, int C, int D, void* stream) {
     if (!x || !W || !y || B <= 0 || C <= 0 || D <= 0) return PA_EINVAL;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, C, D);
+    if (D == 768) hipLaunchKernelGGL(linear_fwd_rows4_kernel<12>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, C);
+    else if (D == 1024) hipLaunchKernelGGL(linear_fwd_rows4_kernel<16>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, C);
+    else hipLaunchKernelGGL(linear_fwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, W, b, y, B, C, D);
     return check_launch();
 }
 

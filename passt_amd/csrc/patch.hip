@@ -37,53 +37,77 @@ __global__ void patch_pos_table_kernel(const float* __restrict__ bias, const flo
     }
 }
 
-// gsum[n][d] = sum_b dtok[b][n][d]
-__global__ void batch_sum_kernel(const float* __restrict__ dtok, int B, int64_t per, float* __restrict__ gsum) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// gsum[n][d] = sum_b dtok[b][n][d]: 16 bytes per thread, four clips in flight (round 5: the scalar one-clip-at-a-time loop ran
+// at 2.9 TB/s)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ dtok, int B, int64_t per, float* __restrict__ gsum) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= per) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dtok[(int64_t)b * per + i];
-    gsum[i] = s;
+    if (((per | i) & 3) == 0) {
+        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+        auto acc = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            const float4 v0 = *(const float4*)(dtok + (int64_t)b * per + i), v1 = *(const float4*)(dtok + (int64_t)(b + 1) * per + i);
+            const float4 v2 = *(const float4*)(dtok + (int64_t)(b + 2) * per + i), v3 = *(const float4*)(dtok + (int64_t)(b + 3) * per + i);
+            acc(s0, v0); acc(s1, v1); acc(s2, v2); acc(s3, v3);
+        }
+        for (; b < B; ++b) acc(s0, *(const float4*)(dtok + (int64_t)b * per + i));
+        acc(s0, s1); acc(s2, s3); acc(s0, s2);
+        *(float4*)(gsum + i) = s0;
+        return;
+    }
+    for (int64_t k = i; k < per && k < i + 4; ++k) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dtok[(int64_t)b * per + k];
+        gsum[k] = s;
+    }
 }
 
-__global__ void patch_param_grads_kernel(const float* __restrict__ gsum, int D, const int32_t* __restrict__ pf,
+// Parameter gradients of the patch stage from gsum[2 + Np][D]: conv bias (all patches), time / frequency position embeddings
+// (the patches of one time / frequency slot), cls / dist tokens and their position rows.  Workgroup = one slot x 16 channels
+// x 16 patch groups: every thread scans Np / 16 patches for its slot (the test is uniform over the 16 channel lanes) and the
+// partial sums meet in LDS.  (Round 5: one thread per (slot, channel) walking all Np patches was 48 us -- 472 dependent
+// L2 round trips on three workgroups for the bias, ~40 per thread for a frequency slot.)
+__global__ __launch_bounds__(256) void patch_param_grads_kernel(const float* __restrict__ gsum, int D, const int32_t* __restrict__ pf,
                                          const int32_t* __restrict__ pt, int Np, int toff, int Tpe, int Fpe,
                                          float* __restrict__ d_cls, float* __restrict__ d_dist, float* __restrict__ d_npe,
                                          float* __restrict__ d_bias, float* __restrict__ d_tpos, float* __restrict__ d_fpos,
                                          int accumulate) {
-    // index space: [D bias+prefix] ++ [Tpe x D time] ++ [Fpe x D freq], the channel d fastest: every gsum read is a
-    // coalesced row segment and the "does patch p belong to this time / frequency slot" test is wave-uniform
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n0 = D, n1 = (int64_t)D * Tpe, n2 = (int64_t)D * Fpe;
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int slot = blockIdx.y;                       // 0: bias + prefix tokens; 1 .. Tpe: time; Tpe + 1 .. Tpe + Fpe: frequency
+    const int d = blockIdx.x * 16 + cx;
     auto put = [&](float* p, float v) { *p = (accumulate ? *p : 0.f) + v; };
-    if (i < n0) {
-        const int d = (int)i;
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent chains: the loop is load-latency bound
-        int p = 0;
-        for (; p + 8 <= Np; p += 8)
+    const int32_t* key = slot == 0 ? nullptr : (slot <= Tpe ? pt : pf);
+    const int want = slot == 0 ? 0 : (slot <= Tpe ? slot - 1 - toff : slot - 1 - Tpe);
+    float s0 = 0.f, s1 = 0.f;
+    if (d < D) {
+        int p = ry;
+        for (; p + 16 < Np; p += 32) {                 // two patches per step: two loads in flight
+            const bool m0 = !key || key[p] == want, m1 = !key || key[p + 16] == want;
+            if (m0) s0 += gsum[(int64_t)(2 + p) * D + d];
+            if (m1) s1 += gsum[(int64_t)(2 + p + 16) * D + d];
+        }
+        if (p < Np && (!key || key[p] == want)) s0 += gsum[(int64_t)(2 + p) * D + d];
+        // (eight keys requested together + unconditional loads of a clamped row times a 0 / 1 weight: 25 us against 21.5)
+    }
+    red[ry][cx] = s0 + s1;
+    __syncthreads();
+    if (ry == 0 && d < D) {
+        float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += gsum[(int64_t)(2 + p + u) * D + d];
-        for (; p < Np; ++p) s8[0] += gsum[(int64_t)(2 + p) * D + d];
-        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        put(d_bias + d, s);
-        put(d_cls + d, gsum[d]);
-        put(d_dist + d, gsum[D + d]);
-        put(d_npe + d, gsum[d]);
-        put(d_npe + D + d, gsum[D + d]);
-    } else if (i < n0 + n1) {
-        const int64_t k = i - n0;
-        const int tt = (int)(k / D), d = (int)(k % D);
-        float s = 0.f;
-        for (int p = 0; p < Np; ++p)
-            if (toff + pt[p] == tt) s += gsum[(int64_t)(2 + p) * D + d];
-        put(d_tpos + (int64_t)d * Tpe + tt, s);
-    } else if (i < n0 + n1 + n2) {
-        const int64_t k = i - n0 - n1;
-        const int f = (int)(k / D), d = (int)(k % D);
-        float s = 0.f;
-        for (int p = 0; p < Np; ++p)
-            if (pf[p] == f) s += gsum[(int64_t)(2 + p) * D + d];
-        put(d_fpos + (int64_t)d * Fpe + f, s);
+        for (int y = 0; y < 16; ++y) s += red[y][cx];
+        if (slot == 0) {
+            put(d_bias + d, s);
+            put(d_cls + d, gsum[d]);
+            put(d_dist + d, gsum[D + d]);
+            put(d_npe + d, gsum[d]);
+            put(d_npe + D + d, gsum[D + d]);
+        } else if (slot <= Tpe) {
+            put(d_tpos + (int64_t)d * Tpe + (slot - 1), s);
+        } else {
+            put(d_fpos + (int64_t)d * Fpe + (slot - 1 - Tpe), s);
+        }
     }
 }
 
@@ -147,11 +171,10 @@ extern "C" int pa_patch_bwd(const float* dtok, int B, int Ntok, int D, const int
         return PA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int64_t per = (int64_t)Ntok * D;
-    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)cdiv(per, 256)), dim3(256), 0, st, dtok, B, per, gsum);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)cdiv(per, 1024)), dim3(256), 0, st, dtok, B, per, gsum);
     int rc = check_launch();
     if (rc) return rc;
-    const int64_t n = (int64_t)D * (1 + Tpe + Fpe);
-    hipLaunchKernelGGL(patch_param_grads_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, gsum, D, patch_f,
+    hipLaunchKernelGGL(patch_param_grads_kernel, dim3((unsigned)cdiv(D, 16), (unsigned)(1 + Tpe + Fpe)), dim3(256), 0, st, gsum, D, patch_f,
                        patch_t, Np, toff, Tpe, Fpe, d_cls, d_dist, d_npe, d_bias, d_time_pos, d_freq_pos, accumulate);
     rc = check_launch();
     if (rc) return rc;

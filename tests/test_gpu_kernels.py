@@ -542,6 +542,52 @@ def test_patch_ops_and_head():
         assert rel_err(sums[j], leaf[idx].grad) < 2e-5, j
 
 
+@pytest.mark.parametrize("B,Np,D,Tpe,Fd,toff,structured", [(8, 472, 768, 99, 12, 17, True), (5, 400, 768, 99, 12, 0, False),
+                                                             (4, 33, 100, 25, 12, 3, False), (66, 40, 96, 50, 12, 2, False)])
+def test_patch_backward_reductions_at_training_shapes(B, Np, D, Tpe, Fd, toff, structured):
+    """pa_patch_bwd's parameter gradients at config #2's geometry (8 kept frequency rows x 59 kept time columns, structured
+    Patchout) and at an unstructured subset (u_patchout): 16 patch groups per slot meeting in LDS, four clips in flight in
+    the batch sum; accumulate on top of existing gradients; odd sizes take the scalar tails"""
+    gen = torch.Generator().manual_seed(5)
+    if structured:
+        fk = torch.randperm(12, generator=gen)[:8].sort().values
+        tk = torch.randperm(Tpe - toff, generator=gen)[:59].sort().values
+        pf = fk.repeat_interleave(59).to(torch.int32)
+        pt = tk.repeat(8).to(torch.int32)
+    else:
+        pf = torch.randint(0, Fd, (Np,), generator=gen, dtype=torch.int32)
+        pt = torch.randint(0, Tpe - toff, (Np,), generator=gen, dtype=torch.int32)
+    assert pf.numel() == Np
+    dtok = rnd(B, Np + 2, D, seed=71).to(DEV)
+    shapes = dict(cls=(1, 1, D), dist=(1, 1, D), npe=(1, 2, D), b=(D,), t=(1, D, 1, Tpe), f=(1, D, Fd, 1))
+    dc = dtok.cpu().double()
+    gs = dc.sum(0)
+    rt = torch.zeros(D, Tpe, dtype=torch.float64)
+    rf = torch.zeros(D, Fd, dtype=torch.float64)
+    rt.index_add_(1, (pt.long() + toff), gs[2:].t().contiguous())
+    rf.index_add_(1, pf.long(), gs[2:].t().contiguous())
+    for accumulate, base in ((False, 5.0), (True, 0.25)):
+        g = {k: torch.full(sh, base, device=DEV) for k, sh in shapes.items()}
+        dpatch = ops.patch_bwd(dtok, pf.to(DEV), pt.to(DEV), toff, Tpe, Fd, g["cls"], g["dist"], g["npe"], g["b"], g["t"], g["f"],
+                               PA_F32, accumulate=accumulate)
+        off = base if accumulate else 0.0
+        assert rel_err(g["cls"].view(-1), gs[0] + off) < 1e-5 and rel_err(g["dist"].view(-1), gs[1] + off) < 1e-5
+        assert rel_err(g["npe"].view(2, D), gs[:2] + off) < 1e-5
+        assert rel_err(g["b"], gs[2:].sum(0) + off) < 1e-5
+        assert rel_err(g["t"].view(D, Tpe), rt + off) < 1e-5 and rel_err(g["f"].view(D, Fd), rf + off) < 1e-5
+        assert rel_err(dpatch, dc[:, 2:].reshape(B * Np, D)) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,D", [(64, 527, 768), (12, 50, 768), (13, 50, 768), (9, 20, 1024), (7, 37, 1100), (21, 10, 64)])
+def test_head_linear_forward_shapes(B, C, D):
+    """pa_linear_f32_fwd: the model widths (768, 1024) take the four-rows-in-flight kernel (batches that are not a multiple of 16
+    included), other widths the plain one"""
+    x, W, b = rnd(B, D, seed=81).to(DEV), rnd(C, D, seed=82, scale=0.1).to(DEV), rnd(C, seed=83).to(DEV)
+    y = ops.linear_f32_fwd(x, W, b)
+    ref = x.cpu().double() @ W.cpu().double().t() + b.cpu().double()
+    assert rel_err(y, ref) < 1e-5
+
+
 def test_mixup_and_optimizers():
     B = 5
     x = rnd(B, 1, 16, 40, seed=36).to(DEV)
