@@ -12,6 +12,11 @@
 //
 // Workgroup = 4 waves = FR_PER_WG consecutive frames of one clip; the output tile is transposed through LDS so every
 // mel row leaves as FR_PER_WG * 4 contiguous bytes.
+// r05 (profiles/r05_mel_probe.txt, tools/probe_mel.py = the PA_MEL_PROBE build): time stamps of every wave's phases showed
+// that half of a frame was the band sums (one lane per band walking its bins: 26 dependent LDS round trips in data-dependent
+// loops).  They are now a lane-local segment recurrence over 8 consecutive bins + ONE segmented DPP scan across the wave
+// (tools/emulate_mel_bands.py is that stage on the CPU); the butterflies use one packed FMA for a -+ i b; 107 -> 90-92 us.
+// The history below is what led here (the "band loops" of r02 are the ones r05 replaced).
 // r03: 16 frames per workgroup instead of 32.  The kernel is latency bound (dependent butterfly chains, two LDS
 // exchanges per frame, ~11 cycles per instruction at two waves per SIMD); 51 KiB of LDS fit THREE workgroups per CU:
 // 133 -> 108 us at B = 64 (8 frames: 106 us but 32-byte output rows).  A persistent variant (workgroups walking the tiles,
