@@ -130,10 +130,10 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int span = (FR_PER_WG - 1) * p.hop + NFFT;
     float* sSig = (float*)smem;                                        // [span] pre-emphasised, reflect-padded
-    char* sScr = smem + ((span * 4 + 15) & ~15);                       // [8 waves][WAVE_SCRATCH]
+    char* sScr = smem + ((span * 4 + 15) & ~15);                       // [MEL_WAVES][WAVE_SCRATCH]
     float* sOut = (float*)(sScr + MEL_WAVES * WAVE_SCRATCH);           // [n_mels][FR_PER_WG + 1]
     // the two per-bin tables are only needed until every lane holds its band-stage constants: they live in the
-    // (not yet written) output tile, which keeps the workgroup under 80 KiB = two workgroups per CU
+    // (not yet written) output tile; 50 KiB per workgroup at 16 frames and hop 320 = three workgroups per CU
     float* sU = sOut;                                                  // [512] up-slope weight of bin k
     int* sJ = (int*)(sU + NC);                                         // [512] triangle index of bin k
 
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
     }
     __syncthreads();
     MEL_STAMP(4);
-    // ---- epilogue: log, SpecAugment masks, affine; rows of 32 frames = 128 contiguous bytes ----
+    // ---- epilogue: log, SpecAugment masks, affine; rows of FR_PER_WG frames = 64 contiguous bytes ----
     for (int idx = tid; idx < p.n_mels * FR_PER_WG; idx += NT) {
         const int mel = idx / FR_PER_WG, fl = idx % FR_PER_WG;
         const int t = f0 + fl;
@@ -413,8 +413,9 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     if (L - 1 <= NFFT / 2) return PA_EUNSUPPORTED;          // reflect padding needs L-1 > n_fft/2 (torch.stft rule)
     if (p->n_frames != pa_mel_num_frames(L, p->hop)) return PA_EINVAL;
     // 16 frames per workgroup (64-byte output rows, three workgroups per CU).  Measured and not adopted (round 5,
-    // profiles/r05_mel_variants.txt): 8 frames per workgroup for grids that leave CUs without their three workgroups (ESC-50 at
-    // batch 12: 375 workgroups): 21.5-22.5 us against 20.6-21.3 -- the per-workgroup set-up is amortised over half the frames
+    // profiles/r05_mel_probe.txt): 8 frames per workgroup -- 125 us against 90 at B = 64, and for grids that leave CUs without
+    // their three workgroups (ESC-50 at batch 12: 384 workgroups) 23-29 us against 19: the per-workgroup set-up (4 us of a 14 us
+    // life) is amortised over half the frames
     const int fr = FR_DEFAULT;
     const int span = (fr - 1) * p->hop + NFFT;
     const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH +
