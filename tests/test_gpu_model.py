@@ -209,6 +209,27 @@ def test_frontend_band_stage_on_other_filterbanks(kw):
     assert torch.equal(mel(torch.from_numpy(wave_np).to(DEV)).cpu(), torch.from_numpy(got))        # deterministic
 
 
+@pytest.mark.parametrize("kw,L", [(dict(hopsize=160), 50000), (dict(hopsize=100), 40001), (dict(hopsize=500, win_length=1024), 64000),
+                                  (dict(win_length=400, n_mels=64), 33333), (dict(hopsize=333, fmin=50.0, fmax=14000), 47000),
+                                  (dict(hopsize=1024), 70000), (dict(hopsize=7), 3000)])
+def test_frontend_other_stft_geometries(kw, L):
+    """STFT hops of the reference's stfthop100 / stfthop160 checkpoints (models/passt.py:219-226) and other hops / windows: the
+    16-byte staging path (spans that are a multiple of four samples) and the plain one, partial last tiles, train mode masks"""
+    kw = dict(dict(fmin_aug_range=10, fmax_aug_range=2000), **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mel = passt_amd.AugmentMelSTFT(**kw).to(DEV)
+    wave_np = G.frontend_inputs(dict(B=3, L=L, seed=93))
+    for training in (False, True):
+        mel.train(training)
+        torch.manual_seed(12)
+        ref = O.mel_frontend(torch.from_numpy(wave_np), training=training, **kw).numpy()
+        torch.manual_seed(12)
+        got = mel(torch.from_numpy(wave_np).to(DEV)).cpu().numpy()
+        assert got.shape == ref.shape
+        assert float(np.abs(got - ref).max()) < 1e-3, (kw, training)
+
+
 def test_module_contract():
     """state_dict schema, parameter order, deepcopy, tuple output."""
     import copy

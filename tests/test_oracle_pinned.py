@@ -207,6 +207,28 @@ def test_oracle_frontend_vs_live_reference():
         assert (ref - got).abs().max().item() < 2e-4
 
 
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("kw", [dict(hopsize=160), dict(hopsize=100), dict(hopsize=500, win_length=1024), dict(win_length=400, n_mels=64),
+                                dict(hopsize=333, fmin=50.0, fmax=14000)])
+def test_oracle_frontend_other_stft_geometries_vs_live_reference(kw):
+    """the reference ships checkpoints for STFT hops of 100 and 160 (models/passt.py:219-226: passt_s_swa_f128_stfthop100 / 160);
+    the oracle's restated STFT (no torch.stft) and filterbank against the live class for those and for other windows / banks"""
+    kw = dict(dict(fmin_aug_range=10, fmax_aug_range=2000), **kw)
+    _, ref_pre = ref_import.load_reference()
+    mel = ref_import.run_silently(ref_pre.AugmentMelSTFT, **kw)
+    wave = torch.from_numpy(G.frontend_inputs(dict(B=2, L=24000, seed=32)))
+    for training in (False, True):
+        mel.train(training)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.manual_seed(4)
+            ref = mel(wave)
+        torch.manual_seed(4)
+        got = O.mel_frontend(wave, training=training, **kw)
+        assert ref.shape == got.shape
+        assert (ref - got).abs().max().item() < 2e-4
+
+
 def test_lr_schedule_matches_reference_ramp():
     """passt_amd.schedule restates helpers/ramp.py; pinned to the live reference when it is mounted, and to the
     closed form otherwise."""
