@@ -267,6 +267,20 @@ CONFIG_CASES = {
     # configs[1]/[2] token geometry: s_patchout_t=40, f=4 => 474 tokens
     "c2_474_tokens": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, num_classes=527, s_patchout_t=40,
                                          s_patchout_f=4), B=2, T=998, seed=74, torch_seed=8),
+    # the reference's other patch strides in TRAINING (models/passt.py: passt_s_swa_p16_s12 / s14 / s16 / s20_128): other patch
+    # grids (10 x 83, 6 x 49, 12 x 62), structured / unstructured Patchout on them, a mixed stride
+    "stride12_train": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, stride=(12, 12), s_patchout_t=30, s_patchout_f=3),
+                           B=2, T=998, seed=75, torch_seed=9),
+    # (990 frames: 49 time patches = the model's 49 time encodings; at 998 frames the convolution yields 50, the reference cuts x
+    # to 49 AFTER taking T_dim = 50 for the Patchout draw and fails whenever index 49 is drawn: test_patchout_past_the_cut...)
+    "stride20_train": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, stride=(20, 20), s_patchout_t=10, s_patchout_f=1),
+                           B=3, T=990, seed=76, torch_seed=10),
+    "stride10x16_train": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, stride=(10, 16), u_patchout=100),
+                              B=2, T=998, seed=77, torch_seed=11),
+    # passt_s_swa_f128_stfthop160_p16_s10_ap473 (models/passt.py:223-226, :1004-1010): a 2000-frame model (STFT hop 160), trained
+    # on 10 s clips = 2000 frames: a 12 x 200 patch grid
+    "stfthop160_2000_frames": dict(cfg=O.make_cfg(embed_dim=768, depth=1, num_heads=12, img_size=(128, 2000), s_patchout_t=80,
+                                                  s_patchout_f=4), B=1, T=2000, seed=78, torch_seed=12),
 }
 
 
@@ -768,6 +782,35 @@ def test_model_speed_test_flow():
     assert not torch.equal(before, net.head[1].bias.detach())
     assert all(torch.isfinite(p).all() for p in net.parameters())
     record("speed_test_flow[B=12]", compiled_vs_f32_logits=e, specs_per_second=r["specs_per_second"])
+
+
+def test_patchout_past_the_cut_fails_like_the_reference():
+    """stride 20 on 998 frames: 50 time patches for 49 time encodings; the reference cuts x to 49 (models/passt.py:524-526) but
+    draws the time Patchout over the 50 it saw before (:512, :535) and indexes out of range whenever 49 is kept (:536).  Product
+    and oracle must fail on exactly the same draws (and agree on the others) -- no silent out-of-range gather."""
+    cfg = O.make_cfg(embed_dim=768, depth=1, num_heads=12, stride=(20, 20), s_patchout_t=10, s_patchout_f=1)
+    case = dict(cfg=cfg, B=2, T=998, seed=79, training=True)
+    m = build(case, "fp32").train()
+    x, _ = G.model_inputs(case)
+    sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]))
+    outcomes = []
+    for seed in range(8):
+        res = []
+        for which in ("oracle", "product"):
+            torch.manual_seed(seed)
+            try:
+                with warnings.catch_warnings(), torch.no_grad():
+                    warnings.simplefilter("ignore")
+                    out = (O.passt_forward(sd, torch.from_numpy(x), cfg, training=True)[0] if which == "oracle"
+                           else m(torch.from_numpy(x).to(DEV))[0].cpu())
+                res.append(out)
+            except IndexError:
+                res.append(None)
+        assert (res[0] is None) == (res[1] is None), seed
+        if res[0] is not None:
+            assert rel(res[1], res[0]) < 1e-3
+        outcomes.append(res[0] is None)
+    assert any(outcomes) and not all(outcomes)        # both behaviours were exercised
 
 
 def test_ensemble_and_other_strides_eval():
