@@ -192,6 +192,54 @@ def test_oracle_vs_live_reference_train_step():
 
 
 @pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("kw,T", [(dict(stride=(12, 12), s_patchout_t=30, s_patchout_f=3), 998),
+                                  (dict(stride=(20, 20), s_patchout_t=10, s_patchout_f=1), 990),
+                                  (dict(stride=(10, 16), u_patchout=100), 998),
+                                  (dict(img_size=(128, 2000), s_patchout_t=80, s_patchout_f=4), 2000),
+                                  (dict(stride=(20, 20), s_patchout_t=10, s_patchout_f=1), 998)])
+def test_oracle_vs_live_reference_other_geometries(kw, T):
+    """the geometries the GPU suite checks the product against the ORACLE for (tests/test_gpu_model.py CONFIG_CASES: other patch
+    strides in training, the 2000-frame model): the oracle itself against the live reference class, gradients included.  Last
+    case: stride 20 on 998 frames -- the reference indexes past its own time cut for some draws (models/passt.py:536) and the
+    restatement has to fail on exactly those."""
+    cfg = O.make_cfg(embed_dim=48, depth=1, num_heads=3, num_classes=11, **kw)
+    sd_np = detgen.passt_state_dict(cfg, 993)
+    x, y = G.model_inputs(dict(cfg=cfg, B=2, T=T, seed=993))
+    m = ref_import.build_reference_passt(cfg, sd_np)
+    m.train()
+    failures = 0
+    for seed in range(4):
+        m.zero_grad()
+        out = []
+        for which in ("reference", "oracle"):
+            torch.manual_seed(seed)
+            try:
+                if which == "reference":
+                    lo, fo = ref_import.run_silently(m, torch.from_numpy(x))
+                else:
+                    sd = O.to_torch(sd_np, requires_grad=True)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        lo, fo = O.passt_forward(sd, torch.from_numpy(x), cfg, training=True)
+                O.bce_loss(lo, torch.from_numpy(y)).backward()
+                out.append((lo.detach(), fo.detach()))
+            except IndexError:
+                out.append(None)
+        assert (out[0] is None) == (out[1] is None), seed
+        if out[0] is None:
+            failures += 1
+            continue
+        assert (out[0][0] - out[1][0]).abs().max().item() < 2e-5 and (out[0][1] - out[1][1]).abs().max().item() < 2e-5
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                assert sd[k].grad is None or sd[k].grad.abs().max().item() == 0.0
+                continue
+            scale = p.grad.abs().max().item()
+            assert (p.grad - sd[k].grad).abs().max().item() <= 2e-4 * scale + 1e-9, (k, seed)
+    assert (failures > 0) == (T == 998 and kw.get("stride") == (20, 20))
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
 def test_oracle_frontend_vs_live_reference():
     _, ref_pre = ref_import.load_reference()
     mel = ref_import.run_silently(ref_pre.AugmentMelSTFT, fmin_aug_range=10, fmax_aug_range=2000)
