@@ -47,3 +47,12 @@ def test_bench_sweep_prints_one_line_per_gpu_count():
     assert [d["n_gpus"] for d in lines] == [1, 2, 4, 8] and all(d["value"] is None and "error" in d and d["steps"] == 3 for d in lines)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep-gpus", "1,x"], env=env, capture_output=True, timeout=300)
     assert r.returncode == 2 and "comma-separated" in json.loads(r.stdout.decode().strip().splitlines()[-1])["error"]
+
+
+def test_instrumented_steps_stay_away_from_the_barrier():
+    """bench.profiled_steps: one timed step in ten carries per-launch events, never step 0 of a run with more than one step (it
+    starts on an empty queue and its first brackets would carry the host's launch latency)"""
+    import bench
+    assert list(bench.profiled_steps(20)) == [5, 15]
+    assert list(bench.profiled_steps(5)) == [4] and list(bench.profiled_steps(2)) == [1] and list(bench.profiled_steps(1)) == [0]
+    assert len(bench.profiled_steps(400)) == 40 and 0 not in bench.profiled_steps(400)
