@@ -138,6 +138,45 @@ def load():
     return lib
 
 
+def compile_opaque(fn):
+    """``torch.compiler.disable`` for a forward that sequences ctypes launches -- WITHOUT importing ``torch._dynamo``.
+
+    torch.compile must see PaSST.forward / AugmentMelSTFT.forward as ONE opaque eager call whichever way a compile is set up:
+    ``torch.compile(net)`` (ex_audioset.py:135), ``net.compile()``, ``torch.compile(net.forward)``, ``torch.compile(step_fn)``
+    with ``net(x)`` somewhere inside.  The wrapper is installed at class definition, so no flow can reach the undecorated
+    function.  ``torch.compiler.disable`` itself would import torch._dynamo (~900 modules, millions of GC-tracked objects)
+    into every process that only wants the eager path: measured +6 ms per training step at ESC-50's batch 12 with bench.py's
+    event bookkeeping (profiles/r05_dynamo_import_gc.txt).  What that decorator does is small and lives in torch._C, which is
+    always loaded: (i) the marker attributes dynamo's tracer looks for (``_torchdynamo_disable``: the call becomes a graph
+    break, not inlined), (ii) ``set_eval_frame(None)`` around the call (nothing below is handed to the frame evaluator), (iii)
+    the wrapper's own code object marked "skip" for the frame evaluator (torch's own wrapper gets that from living in a
+    skip-listed file).  No ``_torchdynamo_orig_callable``: ``torch.compile(net.forward)`` would unwrap it to the unbound
+    function and lose ``self``.  On a torch build without these private entry points: fall back to torch.compiler.disable."""
+    import functools
+
+    import torch
+    try:
+        ef = torch._C._dynamo.eval_frame
+        set_eval_frame = ef.set_eval_frame
+        skip = ef._FrameExecStrategy(ef._FrameAction.SKIP, ef._FrameAction.DEFAULT)
+    except AttributeError:
+        return torch.compiler.disable(fn)
+
+    @functools.wraps(fn)
+    def opaque_forward(*args, **kwargs):
+        prior = set_eval_frame(None)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            set_eval_frame(prior)
+
+    ef.set_code_exec_strategy(opaque_forward.__code__, skip)
+    opaque_forward._torchdynamo_disable = True
+    opaque_forward._torchdynamo_disable_msg = "passt_amd: hand-written HIP kernels behind a C ABI (ctypes); nothing to trace"
+    opaque_forward._torchdynamo_disable_recursive = True
+    return opaque_forward
+
+
 def check(rc, what=""):
     if rc != 0:
         lib = load()

@@ -20,7 +20,15 @@ generator, then ``np.random.beta(alpha, alpha, size)``), the same values bit for
 the live reference function) -- but both results are device tensors uploaded through the library's page-locked staging ring
 (asynchronous copies): ``lam.to(x.device)`` is then a no-op and ``x[rn_indices]`` / ``y[rn_indices]`` index with a device
 tensor, so the step has no host synchronisation left.
+
+CONSTRAINT (the one way this differs from the reference function): with a HIP device visible the results are DEVICE tensors,
+on ``torch.cuda.current_device()`` unless ``device=`` says otherwise.  A caller that indexes CPU tensors with them
+(data-loader-side mixup, ``x_cpu[rn_indices]``) or that never selected its device (``torch.cuda.set_device``; Lightning does)
+must pass ``device="cpu"`` / ``device=x.device``, or set ``PASST_AMD_MIXUP_DEVICE=cpu`` in the environment -- then this IS the
+reference function, CPU results and all.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -35,6 +43,8 @@ def my_mixup(size, alpha, device=None):
     rn_indices = torch.randperm(size)
     beta = np.random.beta(alpha, alpha, size).astype(np.float32)
     lam = torch.from_numpy(np.maximum(beta, np.float32(1.0) - beta))
+    if device is None and os.environ.get("PASST_AMD_MIXUP_DEVICE"):
+        device = os.environ["PASST_AMD_MIXUP_DEVICE"]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     device = torch.device(device)

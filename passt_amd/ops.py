@@ -582,11 +582,19 @@ def wgrad_tn_batched(problems, dtype, partial_ws=None, row_jobs=None):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(lib.pa_gemm_tn_batched(args, len(problems), _stream()), "pa_gemm_tn_batched")
-    check(lib.pa_reduce_partials_batched(red, nred, _stream()), "pa_reduce_partials_batched")
+    # a normal block fills the launch exactly (4 weight gradients + qkv.bias + 2 x 3 LayerNorm rows + fc1.bias = 12 =
+    # PA_REDUCE_BATCH_MAX); anything beyond goes out as a second launch instead of failing in the middle of a backward
+    for lo in range(0, nred, REDUCE_BATCH_MAX):
+        n = min(REDUCE_BATCH_MAX, nred - lo)
+        check(lib.pa_reduce_partials_batched(C.cast(C.byref(red, lo * C.sizeof(ReduceDesc)), C.POINTER(ReduceDesc)), n, _stream()),
+              "pa_reduce_partials_batched")
     if ev0 is not None:
         ev1.record()
         GEMM_PROFILE.setdefault("wgrad_tn", []).append((ev0, ev1, flops))
     return partial_ws
+
+
+REDUCE_BATCH_MAX = 12         # include/passt_amd.h PA_REDUCE_BATCH_MAX
 
 
 def colsum(x, out_f32, accumulate=False):

@@ -21,7 +21,6 @@ Patchout indices are drawn with the reference's own torch CPU RNG calls in the r
 """
 import math
 import os
-import sys
 import warnings
 from collections import OrderedDict
 from functools import partial
@@ -31,26 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import EPI_DGELU, EPI_RESID, EPI_STORE, PA_BF16, PA_F32, PasstAmdError
-
-
-# torch.compile(net) must see the forward as ONE opaque call (see PaSST.forward): torch.compiler.disable.  Applied LAZILY, the first
-# time anything is registered on a module after torch._dynamo was imported (torch.compile(net) builds an OptimizedModule and assigns
-# net to it) or by net.compile(): decorating at import time would import torch._dynamo (~900 modules, millions of GC-tracked
-# objects) into every process that only wants the eager path -- measured on MI355X: with it loaded, Python's cyclic collector costs
-# bench.py's per-launch event bookkeeping +6 ms per step at ESC-50's batch 12 (profiles/r05_dynamo_import_gc.txt).
-_OPAQUE = {"done": False}
-
-
-def make_opaque_to_compile():
-    if _OPAQUE["done"]:
-        return
-    _OPAQUE["done"] = True
-    from . import preprocess
-    PaSST.forward = torch.compiler.disable(PaSST.forward)
-    cls = getattr(preprocess.AugmentMelSTFT, "__wrapped__", preprocess.AugmentMelSTFT)       # (a ba3l command wraps the class)
-    if isinstance(cls, type):
-        cls.forward = torch.compiler.disable(cls.forward)
+from ._lib import EPI_DGELU, EPI_RESID, EPI_STORE, PA_BF16, PA_F32, PasstAmdError, compile_opaque
 
 
 def to_2tuple(x):
@@ -511,6 +491,7 @@ class _PasstFunction(torch.autograd.Function):
                                       "training never asks for one); detach() the input")
         logits, feat, c = passt_forward(model, x, save=True)
         ctx.model, ctx.c = model, c
+        ctx.named, ctx.total = model._graph_params(validate=False)     # the list forward() just handed to apply()
         ctx.set_materialize_grads(False)        # an unused `features` output arrives as None, not as a zero tensor
         return logits, feat
 
@@ -522,7 +503,7 @@ class _PasstFunction(torch.autograd.Function):
                                "pass (retain_graph / double backward are not supported: run the forward again)")
         # gradient buffers for EVERY parameter the backward writes (all but head_dist.*): the kernel sequence produces
         # them all; parameters with requires_grad=False are simply not handed back to autograd (frozen backbone, ...)
-        named, total = model._graph_params()
+        named, total = ctx.named, ctx.total
         flat = torch.empty(total, device=dlogits.device, dtype=torch.float32)
         # one C++ call makes the 159 views (a Python loop of slice + view costs 1.3 ms of host time in front of the first
         # backward kernel: exposed whenever the caller synchronised in this step, and the reference's mixup does)
@@ -558,21 +539,12 @@ class _PasstFunction(torch.autograd.Function):
         return tuple(out)
 
 
-# Every registration of a parameter or sub-module on ANY nn.Module bumps this counter (torch's global registration hooks: an
-# integer increment each): PaSST._graph_params() keys its cached parameter list on it, so surgery anywhere in the tree
-# (net.head[1] = nn.Linear(768, 50), replacing a block's sub-module) is seen by the next forward without re-walking
-# named_parameters() on every call.
-_TREE_EPOCH = [0]
-
-
-def _bump_tree_epoch(*_a):
-    _TREE_EPOCH[0] += 1
-    if not _OPAQUE["done"] and "torch._dynamo" in sys.modules:       # somebody is about to compile: see make_opaque_to_compile()
-        make_opaque_to_compile()
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_tree_epoch)
-torch.nn.modules.module.register_module_module_registration_hook(_bump_tree_epoch)
+def _tree_signature(root):
+    """[(module, ids of its parameters, ids of its sub-modules)] over the module tree: what PaSST._graph_params() validates its
+    cached parameter list against on every forward (~110 modules, two small tuples each: ~30 us).  Local to this model: surgery
+    anywhere in ITS tree (net.head[1] = nn.Linear(768, 50), a block's sub-module replaced, a parameter re-registered) changes
+    a tuple; nothing is hooked process-wide."""
+    return [(m, tuple(map(id, m._parameters.values())), tuple(map(id, m._modules.values()))) for m in root.modules()]
 
 
 class PaSST(nn.Module):
@@ -650,15 +622,21 @@ class PaSST(nn.Module):
         self.__dict__.update(d)
         self._reset_runtime()
 
-    def _graph_params(self):
+    def _graph_params(self, validate=True):
         """([(name, parameter)] without head_dist.*, total numel): what the autograd node takes and returns gradients for, in
-        named_parameters() order.  Cached (walking the module tree costs 0.4 ms per call, twice per step); dropped whenever a
-        parameter or sub-module is registered on any module (``_TREE_EPOCH``: surgery anywhere in the tree, e.g.
-        ``net.head[1] = nn.Linear(768, 50)``) or the module is moved / cast (``_apply``)."""
+        named_parameters() order.  Cached (named_parameters() over the tree costs 0.4 ms per call); the cache is validated per
+        forward against the identity of every module's parameters and children (``_tree_signature``: the cached list keeps the
+        old objects alive, so an id cannot be reused), and dropped when the module is moved / cast (``_apply``).  The backward
+        of a forward passes validate=False: it must hand back gradients for exactly the list that forward gave to apply()."""
         hit = self._scratch.get("graph_params")
-        if hit is None or hit[2] != _TREE_EPOCH[0]:
+        if hit is not None and validate:
+            for m, pids, mids in hit[2]:
+                if tuple(map(id, m._parameters.values())) != pids or tuple(map(id, m._modules.values())) != mids:
+                    hit = None
+                    break
+        if hit is None:
             named = [(n, p) for n, p in self.named_parameters() if not n.startswith("head_dist.")]
-            hit = self._scratch["graph_params"] = (named, sum(p.numel() for _, p in named), _TREE_EPOCH[0])
+            hit = self._scratch["graph_params"] = (named, sum(p.numel() for _, p in named), _tree_signature(self))
         return hit[:2]
 
     def __setattr__(self, name, value):
@@ -711,17 +689,13 @@ class PaSST(nn.Module):
         """Call after updating parameters through raw device pointers (passt_amd.optim does)."""
         self._staged.epoch += 1
 
-    def compile(self, *args, **kwargs):
-        """nn.Module.compile (in-place torch.compile of __call__): the forward stays one opaque eager call, see forward()."""
-        import torch._dynamo  # noqa: F401
-        make_opaque_to_compile()
-        return super().compile(*args, **kwargs)
-
+    @compile_opaque
     def forward(self, x):
         """x: (B,1,F,T) -> (logits (B,C), features (B,D)); always a tuple (models/passt.py:588,595).
 
         ``torch.compile(net)`` (ex_audioset.py:135, model_speed_test :391): the whole forward is ONE opaque call to the
-        compiler (``torch.compiler.disable``, installed by make_opaque_to_compile() when a compile is set up) -- there is nothing for Inductor to fuse, every kernel of the network is already
+        compiler (``_lib.compile_opaque``: torch.compiler.disable's mechanism without the torch._dynamo import, installed at class
+        definition so that every compile flow meets it) -- there is nothing for Inductor to fuse, every kernel of the network is already
         a hand-written launch behind the C ABI, and dynamo cannot trace ctypes calls; the compiled module therefore runs this
         function eagerly, captures no graph and never recompiles (tests/test_abi_cpu.py, tests/test_gpu_model.py speed-test
         flow).  Under ``torch.autocast`` of either 16-bit type (Lightning precision=16 / torch.cuda.amp.autocast() are fp16) the

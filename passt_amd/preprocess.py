@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import MelParams, PasstAmdError
+from ._lib import MelParams, PasstAmdError, compile_opaque
 
 
 def _draw_mask(mask_param, size):
@@ -85,7 +85,8 @@ class AugmentMelSTFT(nn.Module):
         self.register_buffer("_bin_mel", bin_mel.float(), persistent=False)
         self.register_buffer("_twiddle", tw.float().contiguous(), persistent=False)
 
-    def forward(self, x):           # (opaque to torch.compile like PaSST.forward: passt.make_opaque_to_compile)
+    @compile_opaque                 # ONE opaque eager call under torch.compile, like PaSST.forward
+    def forward(self, x):
         if not x.is_cuda:
             raise PasstAmdError("passt_amd.AugmentMelSTFT runs on a HIP device only (no CPU fallback)")
         if x.dim() != 2:

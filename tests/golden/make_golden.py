@@ -63,6 +63,18 @@ B64_CASES = {
     "model_passt_s_train_b64_ones": dict(cfg=O.make_cfg(s_patchout_t=40, s_patchout_f=4), B=64, T=998, training=True,
                                          seed=26, torch_seed=6465, compact=True, inputs="ones"),
 }
+# r06: the two remaining bench configurations at THEIR benchmarked batch.  BASELINE config #4 exactly (1024/24/16, u_patchout
+# 400 => 790 tokens, B = 32: M = 25 280 token rows; the reference runs with its blocks under torch.utils.checkpoint -- the
+# arithmetic is the same, recomputed, and 24 blocks of saved (32,16,790,790) score tensors would not fit this container's
+# 64 GB) and config #5 exactly (ESC-50 fine-tune, ex_esc50.py:40,60: n_classes 50, B = 12, 500 frames into the 998-frame model,
+# s_patchout_t 10 / f 3 => 353 tokens, M = 4 236: the split-K path of every [M, 768] GEMM and the two-kernel attention
+# backward; class-index targets and the CE loss of ex_esc50.py:166-168).
+BENCH_CASES = {
+    "model_vitl_u400_train_b32": dict(cfg=O.make_cfg(embed_dim=1024, depth=24, num_heads=16, u_patchout=400), B=32, T=998,
+                                      training=True, seed=27, torch_seed=3232, compact=True, checkpoint=True),
+    "model_esc50_train_b12": dict(cfg=O.make_cfg(num_classes=50, s_patchout_t=10, s_patchout_f=3), B=12, T=500, training=True,
+                                  seed=28, torch_seed=1212, compact=True, loss="ce"),
+}
 FRONTEND_CASES = {
     "frontend_eval": dict(B=2, L=32000, training=False, seed=21,
                           kw=dict(fmin_aug_range=10, fmax_aug_range=2000)),
@@ -80,6 +92,8 @@ def model_inputs(case):
     if case.get("inputs") == "ones":                     # model_speed_test's batch (ex_audioset.py:384-385)
         return (np.ones((B, 1, cfg["img_size"][0], T), np.float32), np.ones((B, cfg["num_classes"]), np.float32))
     x = detgen.uniform(case["seed"], "x", (B, 1, cfg["img_size"][0], T), -1.5, 1.5)
+    if case.get("loss") == "ce":                         # class ids (ex_esc50.py:166)
+        return x, np.floor(detgen.uniform(case["seed"], "y", (B,), 0.0, float(cfg["num_classes"]))).astype(np.int64).clip(0, cfg["num_classes"] - 1)
     y = (detgen.uniform(case["seed"], "y", (B, cfg["num_classes"]), 0.0, 1.0) < 0.1).astype(np.float32)
     return x, y
 
@@ -110,11 +124,19 @@ def gen_model_case(name, case):
     m = ref_import.build_reference_passt(cfg, sd)
     m.train(case["training"])
     out = {}
+    if case.get("checkpoint"):
+        # the reference's own Block.forward, run under activation checkpointing (same arithmetic, recomputed in the backward)
+        from torch.utils.checkpoint import checkpoint
+        for blk in m.blocks:
+            blk.forward = (lambda x_, f=blk.forward: checkpoint(f, x_, use_reentrant=False))
     if case["training"]:
         torch.manual_seed(case["torch_seed"])
         logits, feat = ref_import.run_silently(m, torch.from_numpy(x))
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(
-            logits, torch.from_numpy(y), reduction="none").mean()          # ex_audioset.py:184-186
+        if case.get("loss") == "ce":
+            loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(y), reduction="none").mean()   # ex_esc50.py:166-167
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(
+                logits, torch.from_numpy(y), reduction="none").mean()          # ex_audioset.py:184-186
         loss.backward()
         out["loss"] = np.float32(loss.item())
         for k, p in m.named_parameters():
@@ -239,6 +261,11 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "b64":       # config #2 at the benchmarked batch
         for n, c in B64_CASES.items():
+            if len(sys.argv) < 3 or n in sys.argv[2:]:
+                gen_model_case(n, c)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":     # configs #4 / #5 at their benchmarked batch (r06)
+        for n, c in BENCH_CASES.items():
             if len(sys.argv) < 3 or n in sys.argv[2:]:
                 gen_model_case(n, c)
         sys.exit(0)

@@ -708,6 +708,56 @@ def test_config2_batch64_vs_reference_golden(golden_dir, name, precision):
            worst_grad_trainstep=w_t, worst_grad_norm_trainstep=wn_t)
 
 
+# ---- r06: BASELINE configs #4 and #5 at THEIR benchmarked batch, reference-generated ------------------------------------
+@pytest.mark.parametrize("name", list(G.BENCH_CASES))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bench_batch_vs_reference_golden(golden_dir, name, precision):
+    """The two bench configurations that were pinned at a small batch only, at the batch bench.py times
+    them at, against fixtures the REAL reference produced on CPU (make_golden.py bench):
+    config #4 -- 1024/24/16, u_patchout 400 (790 tokens), B = 32: M = 25 280 token rows, 16 heads, 24 blocks, the unstructured
+    gather; config #5 -- ESC-50 fine-tune (ex_esc50.py:40,60): n_classes 50, B = 12, 500 frames into the 998-frame model (random
+    time-positional offset), s_patchout t = 10 / f = 3 (353 tokens), M = 4 236: the split-K path of every [M, 768] GEMM, the
+    two-kernel attention backward, CE loss on class ids (ex_esc50.py:166-167).  Both product paths, like
+    test_config2_batch64_vs_reference_golden: the autograd node and TrainStep(use_mixup=False, lr=0)."""
+    case = G.BENCH_CASES[name]
+    gold = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    ce = case.get("loss") == "ce"
+    ltol = 1e-5 if precision == "fp32" else 2e-3
+    m = build(case, precision).train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(case["torch_seed"])
+        logits, feat = m(xg)
+        if ce:
+            loss = torch.nn.functional.cross_entropy(logits, yg, reduction="none").mean()
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, yg, reduction="none").mean()
+        loss.backward()
+    e_l, e_f = rel(logits.detach().cpu(), gold["logits"]), rel(feat.detach().cpu(), gold["features"])
+    lim = 1e-3 if precision == "fp32" else BF16_LOGITS
+    assert e_l < lim and e_f < lim, (e_l, e_f)
+    assert abs(loss.item() - float(gold["loss"])) < ltol
+    for k, p in m.named_parameters():
+        if "gradnone." + k in gold:
+            assert p.grad is None, k
+    w_a, wn_a = _check_b64_grads([(k, p.grad) for k, p in m.named_parameters() if "grad." + k in gold], gold, precision, "autograd")
+    del m, logits, feat, loss
+    from passt_amd.train import TrainStep
+    m = build(case, precision).train()
+    ts = TrainStep(m, mel=None, lr=0.0, weight_decay=0.0, use_mixup=False, loss="ce" if ce else "bce")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(case["torch_seed"])
+        loss_t = ts.step(xg, yg)
+    assert abs(float(loss_t.item()) - float(gold["loss"])) < ltol
+    w_t, wn_t = _check_b64_grads([(k, ts.grads[k]) for k, _ in ts.named], gold, precision, "trainstep")
+    ts.close()
+    record(f"{name}[{precision}]", logits=e_l, features=e_f, worst_grad_autograd=w_a, worst_grad_norm_autograd=wn_a,
+           worst_grad_trainstep=w_t, worst_grad_norm_trainstep=wn_t)
+
+
 def test_block_finishing_launch_equals_separate_reductions():
     """Round 5: the two LayerNorms' dgamma | dbeta (+ the bias gradient each carries) and the GELU' epilogue's fc1.bias rows of a
     block are reduced by the SAME finishing launch as the split-K slabs of its weight gradients (pa_reduce_partials_batched,
