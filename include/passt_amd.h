@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 5   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
+#define PA_ABI_VERSION 6   /* 2 (round 3): pa_attention_* take flags, pa_attention_bwd workspace query, pa_gemm_args.colscale*;
                             * 3: pa_gemm_nt_splitk*;  4 (round 4): pa_comm_info, pa_adamw_dev / pa_adamw_hyper, PA_GEMM_EPILOGUE_V3;
-                            * 5 (round 5): PA_ATTN_BWD_TWO_PASS (pa_attention_bwd defaults to the single-pass kernel where it applies) */
+                            * 5 (round 5): PA_ATTN_BWD_TWO_PASS (pa_attention_bwd defaults to the single-pass kernel where it applies);
+                            * 6 (round 6): pa_adamw_stage (optimizer update + GEMM-ready weight copies in one pass) */
 
 enum { PA_F32 = 0, PA_BF16 = 1 };
 
@@ -303,9 +304,13 @@ int pa_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumul
  * (sequence, head): S / dP / exp formed once, dQ contracted over all keys through an LDS transposition buffer; `delta` is then not
  * touched) instead of the dQ kernel followed by the dK/dV kernel: same quantities, both deterministic.  By default the library
  * picks the single pass when B * H >= 512 (two rounds of 256 CUs).  PA_ATTN_BWD_TWO_PASS forces the kernel pair,
- * PA_ATTN_BWD_SINGLE_PASS the single kernel wherever it applies (elsewhere it is ignored). */
+ * PA_ATTN_BWD_SINGLE_PASS the single kernel wherever it applies (elsewhere it is ignored).
+ * PA_ATTN_BWD_SINGLE_PASS_W16 (ABI 6): the single kernel in its sixteen-wave form (1024 threads, four waves per SIMD, one
+ * 32-key block per wave) wherever the single pass applies -- same quantities; measured against the eight-wave form in
+ * profiles/r06_attention_w16.txt. */
 #define PA_ATTN_BWD_TWO_PASS 2
 #define PA_ATTN_BWD_SINGLE_PASS 4
+#define PA_ATTN_BWD_SINGLE_PASS_W16 8
 int pa_attention_fwd(const void* qkv, int ldqkv, void* o, int ldo, float* lse, int B, int H, int N, int nq,
                      float scale, int dtype, int flags, void* stream);
 /* number of floats of pa_attention_bwd's `delta` workspace */
@@ -401,6 +406,27 @@ int pa_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
  * part of a captured hipGraph (passt_amd.train.TrainStep(graph=True)). */
 int pa_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
 void pa_adamw_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* hyper7_host);
+/* AdamW of one bucket of the flat buffers AND the GEMM-ready copies of its weight matrices in ONE launch (ABI 6): what
+ * pa_adamw followed by pa_stage_weights produce -- parameters, moments and copies bit-identical -- without reading the updated
+ * parameters back (torch.optim.AdamW, ex_audioset.py:104-109; the copies have no reference counterpart: AMP autocast casts the
+ * weights per op).  `descs` (DEVICE memory, n_desc entries, in work-item order) lists every parameter of the bucket:
+ *   offset      element offset of the parameter in p / g / m / v
+ *   rows, cols  its shape as a row-major matrix (a parameter without copies: rows = 1, cols = numel)
+ *   dst, dst_t  where non-NULL: the straight cast [rows][cols] and the transposed cast [cols][rows] of `dtype`, contiguous
+ *   tile_begin  running count of work items: ceil(rows/64)*ceil(cols/64) tiles of 64x64 for a parameter with a copy,
+ *               ceil(numel/4096) runs for one without;  total_items = their sum (= the grid).
+ * hyper_dev == NULL: the step's scalars by value, as pa_adamw;  else the 7 device floats of pa_adamw_dev (by-value ones ignored). */
+typedef struct pa_adamw_stage_desc {
+    int64_t offset;
+    void* dst;
+    void* dst_t;
+    int32_t rows, cols;
+    int32_t tile_begin;
+    int32_t reserved;
+} pa_adamw_stage_desc;
+int pa_adamw_stage(float* p, const float* g, float* m, float* v, const pa_adamw_stage_desc* descs, int n_desc, int total_items,
+                   int dtype, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   const float* hyper_dev, void* stream);
 /* torch.optim.SGD lr only (ex_audioset.py:392 model_speed_test) */
 int pa_sgd(float* p, const float* g, int64_t n, float lr, void* stream);
 /* Stochastic weight averaging step on flat buffers (helpers/swa_callback.py:246-268, update_parameters + avg_fn):

@@ -43,6 +43,10 @@ class StageDesc(C.Structure):          # == pa_stage_desc
     _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("rows", i32), ("cols", i32), ("tile_begin", i32), ("reserved", i32)]
 
 
+class AdamwStageDesc(C.Structure):     # == pa_adamw_stage_desc
+    _fields_ = [("offset", i64), ("dst", vp), ("dst_t", vp), ("rows", i32), ("cols", i32), ("tile_begin", i32), ("reserved", i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/passt_amd.h declares
 SIGNATURES = {
     "pa_abi_version": (i32, []),
@@ -94,6 +98,7 @@ SIGNATURES = {
     "pa_mixup": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "pa_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "pa_adamw_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "pa_adamw_stage": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, i32, vp, vp]),
     "pa_adamw_hyper": (None, [f32, f32, f32, f32, f32, i32, C.POINTER(f32)]),
     "pa_sgd": (i32, [vp, vp, i64, f32, vp]),
     "pa_swa_update": (i32, [vp, vp, i64, i32, vp]),
@@ -132,7 +137,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.restype, fn.argtypes = res, args
-    if lib.pa_abi_version() != 5:      # include/passt_amd.h PA_ABI_VERSION
+    if lib.pa_abi_version() != 6:      # include/passt_amd.h PA_ABI_VERSION
         raise PasstAmdError("libpasst_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -888,13 +888,20 @@ __device__ __forceinline__ bf16x8 tr_frag(uint32_t a0, uint32_t a1, int imm) {
     return f;
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_fused_kernel(
+// W16 (round 6): the same kernel with SIXTEEN waves of 32 keys (1024 threads, four waves per SIMD, <= 128
+// registers) instead of eight waves of 64 keys: twice the independent chains per SIMD in front of the same LDS round trips.  One
+// key block per wave (dK / dV accumulators 64 registers); the LDS image is unchanged; the Q / dO stage requests and phase 2 (eight
+// 16 x 16 tiles of dQ^T) are done by waves 0-7 -- two per SIMD (a workgroup's waves go round the SIMDs in fours).
+template <bool W16>
+__global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(W16 ? 4 : 2, W16 ? 4 : 2))) void attn_bwd_fused_kernel(
     const bf16* __restrict__ qkv, int ldqkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int ldo,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, int lddqkv, int H, int N, float scale) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using T = bf16;
     using F = bf16x8;
     constexpr int NF = 4, NS = 2;
+    constexpr int NKB = W16 ? 1 : 2;                             // 32-key blocks per wave
+    constexpr int NT = W16 ? 1024 : 512;                         // threads
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.x;
@@ -920,8 +927,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         const char* gK = (const char*)(base + D);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rq = wave * 8 + i;
+        for (int i = 0; i < 4 * NKB; ++i) {
+            const int rq = wave * (4 * NKB) + i;
             const int row = rq * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz_f128(row);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gK + (int64_t)min(row, N - 1) * ldbq + c * 16),
@@ -929,37 +936,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 4 * FT_PLANE / (512 * 16); ++i) *(u32x4*)(sT + (i * 512 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < 4 * FT_PLANE / (NT * 16); ++i) *(u32x4*)(sT + (i * NT + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
-    // Q / dO tile t -> stage buffer: 8 requests of 8 rows, one per wave (waves 0-3: Q, 4-7: dO)
-    const int st_tensor = wave >> 2, st_piece = wave & 3;
+    // Q / dO tile t -> stage buffer: 8 requests of 8 rows, one per wave (waves 0-3: Q, 4-7: dO; W16: waves 8-15 request nothing)
+    const int st_tensor = (wave >> 2) & 1, st_piece = wave & 3;
     const int st_row = st_piece * 8 + (lane >> 3);
     const int st_chunk = ((lane & 7) ^ swz_f128(st_row)) * 16;
     const char* st_src = st_tensor ? (const char*)dobase : (const char*)base;
     const int st_ldb = st_tensor ? ldbo : ldbq;
     auto stage = [&](int t) __attribute__((always_inline)) {
+        if (W16 && wave >= 8) return;
         const int grow = min(t * 32 + st_row, N - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st_src + (int64_t)grow * st_ldb + st_chunk),
                                          (__attribute__((address_space(3))) void*)(sStage + (t & 1) * F_STAGE + st_tensor * 4096 + st_piece * 1024), 16, 0, 0);
     };
     stage(0);
-    const int kbase0 = wave * 64;
-    F vf[2][NF];                                                 // V row fragments of this wave's keys (B operand of the dP products)
+    const int kbase0 = wave * (32 * NKB);
+    F vf[NKB][NF];                                               // V row fragments of this wave's keys (B operand of the dP products)
+    // W16 has no 16 registers to keep them in: they are fetched again for every tile (four 16-byte loads per lane out of the L2,
+    // requested at the top of the block, used behind the score chain and the exponentials) from this per-lane row pointer
+    const T* vrow = base + 2 * D + (int64_t)min(kbase0 + l31, N - 1) * ldqkv + hf * 8;
+    if constexpr (!W16) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int krow = min(kbase0 + kb * 32 + l31, N - 1);
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int krow = min(kbase0 + kb * 32 + l31, N - 1);
 #pragma unroll
-        for (int s = 0; s < NF; ++s) vf[kb][s] = *(const F*)(base + 2 * D + (int64_t)krow * ldqkv + (s * 2 + hf) * 8);
+            for (int s = 0; s < NF; ++s) vf[kb][s] = *(const F*)(base + 2 * D + (int64_t)krow * ldqkv + (s * 2 + hf) * 8);
+        }
     }
     // per-query scalars in the form the score chains take as C operand: -lse * log2(e), -delta = -rowsum(dO * O).  Wave w owns
-    // queries [64 w, 64 w + 64).  Queries past N (last tile; their Q / dO rows are copies of row N - 1) get the C operand -inf:
+    // queries [32 NKB w, 32 NKB (w + 1)).  Queries past N (last tile; their Q / dO rows are copies of row N - 1) get the C operand -inf:
     // P = exp2(-inf) = 0 and dS = P * finite = 0 -- they contribute nothing to dK / dV and no tile needs a mask.
     {
         // two lanes per row (what the dQ kernel of the two-kernel backward does)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int q = wave * 64 + r * 32 + l31;
-            if (wave * 64 + r * 32 < nt * 32) {                  // wave-uniform
+        for (int r = 0; r < NKB; ++r) {
+            const int q = wave * (32 * NKB) + r * 32 + l31;
+            if (wave * (32 * NKB) + r * 32 < nt * 32) {          // wave-uniform
                 const int qrow = min(q, N - 1);
                 float dlt = 0.f;
 #pragma unroll
@@ -1001,9 +1014,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto ld128 = [](uint32_t addr) { return *(const __attribute__((address_space(3))) F*)(size_t)addr; };
     auto ld4f = [](uint32_t addr) { return *(const __attribute__((address_space(3))) f32x4*)(size_t)addr; };
     auto st64 = [](uint32_t addr, uint32_t w0, uint32_t w1) { *(__attribute__((address_space(3))) u32x2_t*)(size_t)addr = u32x2_t{w0, w1}; };
-    f32x16 dk[2][2], dv[2][2];
+    f32x16 dk[NKB][2], dv[NKB][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int db = 0; db < 2; ++db) { dk[kb][db] = acc_splat(0.f); dv[kb][db] = acc_splat(0.f); }
 
@@ -1023,6 +1036,80 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) sa[4 * g + e] = a[e];
         }
+        F pfp[NS];                                               // W16: P as bf16 fragments (sa is dead after the exponentials)
+        F cf[4];
+        auto issue_cf = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                cf[db] = tr_frag(aC[db][0], aC[db][1], ODO + 16 * st * 128);
+                cf[2 + db] = tr_frag(aC[db][0], aC[db][1], OQ + 16 * st * 128);
+            }
+        };
+        if constexpr (W16) {
+            // The sixteen-wave form has 128 registers: 64 of accumulators, 16 of V fragments, ~10 of addresses.  So: fragments of
+            // the score chain two k-steps deep (16 registers, not 32); the exponentials right behind it and P packed to bf16 at once
+            // (what the dV product takes anyway: 8 registers instead of 16 across the dP chain; dS = bf16(P) * dP', one more
+            // rounding of P than the eight-wave form); dO fragments two deep; column fragments requested after the arithmetic.
+#pragma unroll
+            for (int st = 0; st < NF; ++st) vf[0][st] = *(const F*)(vrow + st * 16);
+            if (!(PA_FUSED_ABL & 8)) {
+                F qf[2], kf[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    qf[st] = lds_b128_imm<F>(aS[st], OQ);
+                    kf[st] = lds_b128_imm<F>(aS[st] + (uint32_t)kdelta, kb * 4096);
+                }
+#pragma unroll
+                for (int st = 0; st < NF; ++st) {
+                    frag_settle(qf[st & 1], kf[st & 1], st + 1 < NF ? 2 : 0);
+                    mma32<T>(sa, qf[st & 1], kf[st & 1]);
+                    if (st + 2 < NF) {
+                        qf[st & 1] = lds_b128_imm<F>(aS[st + 2], OQ);
+                        kf[st & 1] = lds_b128_imm<F>(aS[st + 2] + (uint32_t)kdelta, kb * 4096);
+                    }
+                }
+            }
+            if (!(PA_FUSED_ABL & 2)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sa[r] = __builtin_amdgcn_exp2f(sa[r]);
+            }
+#pragma unroll
+            for (int st = 0; st < NS; ++st) pfp[st] = acc_frag<T>(sa, st);
+            // pin the order (volatile asm statements keep theirs, and the fragment loads of the dP chain are such): left alone the
+            // scheduler sinks the exponentials and the packing to the products, keeping 16 + 16 accumulator registers live through the
+            // dP chain and spilling a dK / dV block around every product group
+            asm volatile("" : "+v"(pfp[0]), "+v"(pfp[1]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 d = ld4f(sc + FK * 4 + g * 32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dpa[4 * g + e] = d[e];
+            }
+            if (!(PA_FUSED_ABL & 8)) {
+                F df[2];
+#pragma unroll
+                for (int st = 0; st < 2; ++st) df[st] = lds_b128_imm<F>(aS[st], ODO);
+#pragma unroll
+                for (int st = 0; st < NF; ++st) {
+                    frag_settle1(df[st & 1], st + 1 < NF ? 1 : 0);
+                    mma32<T>(dpa, df[st & 1], vf[kb][st]);
+                    if (st + 2 < NF) df[st & 1] = lds_b128_imm<F>(aS[st + 2], ODO);
+                }
+            }
+            // the next tile's Q / dO rows are requested HERE, behind the only vector-memory loads of the block (the V fragments above:
+            // the compiler's wait for them is then exact, nothing younger is in flight) and in front of half a tile of work
+            if (t + 1 < nt) stage(t + 1);
+            if (!(PA_FUSED_ABL & 2)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpa[r] *= (float)pfp[r >> 3][r & 7];       // dS / scale
+            }
+            if (PA_FUSED_ABL & 4) {
+                asm volatile("" :: "v"(pfp[0]), "v"(pfp[1]), "v"(dpa));
+                return;
+            }
+            issue_cf(0);
+        } else {
         // the fragment reads are asm (issued where they are written, settled by counted waits): left to itself the compiler, at
         // the register limit, either hoists all twelve loads and spills the V fragments or serialises load -> wait -> MFMA
         if (!(PA_FUSED_ABL & 8)) {
@@ -1048,14 +1135,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (column fragments single-buffered: 16 registers, not 32 -- the kernel sits at the 256-register limit of two waves per
         // SIMD, and a spilled accumulator inside the tile loop drains the Q / dO prefetch in front of its reload.  The first
         // set is requested in front of the dP chain / the exponentials, which cover its latency)
-        F cf[4];
-        auto issue_cf = [&](int st) __attribute__((always_inline)) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                cf[db] = tr_frag(aC[db][0], aC[db][1], ODO + 16 * st * 128);
-                cf[2 + db] = tr_frag(aC[db][0], aC[db][1], OQ + 16 * st * 128);
-            }
-        };
         if (!(PA_FUSED_ABL & 8)) {
             F df[NF];
 #pragma unroll
@@ -1080,11 +1159,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("" :: "v"(sa), "v"(dpa));
             return;
         }
+        }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key] ; T[key][q] = bf16(dS)
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             if (st > 0) issue_cf(st);
-            const F pf = acc_frag<T>(sa, st), dsf = acc_frag<T>(dpa, st);
+            F pf;
+            if constexpr (W16) pf = pfp[st];
+            else pf = acc_frag<T>(sa, st);
+            const F dsf = acc_frag<T>(dpa, st);
             col_settle<0>(cf[0], cf[1], cf[2], cf[3]);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -1095,8 +1178,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 w = __builtin_bit_cast(u32x4, dsf);
             const int TOFF = BUF * (2 * FT_PLANE) + st * FT_PLANE + kb * 1024;
-            st64(aT0 + TOFF, w[0], w[1]);
-            st64((aT0 ^ 16u) + TOFF, w[2], w[3]);
+            // lanes whose key is past N keep their hands off T (its rows behind key N - 1 stay the prologue's zeros): their score
+            // is exp2(-lse * log2 e) -- the K row is zero --, which overflows for a query with lse < -88 (short sequences, strongly
+            // negative logits), and inf or NaN in T times the zero K rows of phase 2 would be NaN in dQ of VALID queries.  In their
+            // own dK / dV columns (never stored) anything may stand.  Nothing asm-issued is in flight here (settled above).
+            uint32_t tl = (uint32_t)lane;
+            asm volatile("" : "+v"(tl));                         // formed here (two VALU), not carried through the block in a register
+            if (kbase0 + kb * 32 + (int)(tl & 31u) < N) {
+                st64(aT0 + TOFF, w[0], w[1]);
+                st64((aT0 ^ 16u) + TOFF, w[2], w[3]);
+            }
         }
     };
     // phase 2 of tile t: dQ^T tile (d16, q16) = sum over keys, 4 NCH steps of 32 keys.  Straight-line: the transposed reads are
@@ -1153,7 +1244,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     // K rows behind the last key := 0 (so that the dS columns of lanes past N, and the T rows nobody writes, contribute nothing
     // to dQ); the scores of those lanes become exp2(-lse): finite
-    for (int i = tid; i < (nk4 * 32 - N) * 8; i += 512) {
+    for (int i = tid; i < (nk4 * 32 - N) * 8; i += NT) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         *(u32x4*)(sK + (N + (i >> 3)) * 128 + (i & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -1163,7 +1254,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using NCH = std::integral_constant<int, 4>;      // phase 2 walks the whole K tile (16 steps of 32 keys) whatever N is
     auto phase1 = [&](auto buf_tag, int t) __attribute__((always_inline)) {
         if (kbase0 < N) block(std::integral_constant<int, 0>{}, buf_tag, t);
-        if (kbase0 + 32 < N) block(std::integral_constant<int, 1>{}, buf_tag, t);
+        else if (W16 && t + 1 < nt) stage(t + 1);                // (W16 requests the next tile from inside the block)
+        if constexpr (NKB == 2) {
+            if (kbase0 + 32 < N) block(std::integral_constant<int, 1>{}, buf_tag, t);
+        }
     };
     auto sync = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1173,10 +1267,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // inter-barrier interval in OPPOSITE orders -- two loop nests chosen once per wave.  The second nest costs the allocator four
     // spilled registers per tile, and a reload inside the tile loop waits for the Q / dO prefetch in flight: 270-277 us against 183.)
     auto tile = [&](auto buf_tag, int t) __attribute__((always_inline)) {
-        if (t + 1 < nt) stage(t + 1);
+        if (!W16 && t + 1 < nt) stage(t + 1);
         phase1(buf_tag, t);
         sync();
-        if (!(PA_FUSED_ABL & 1)) phase2(buf_tag, NCH{}, t);
+        if (!(PA_FUSED_ABL & 1) && (!W16 || wave < 8)) phase2(buf_tag, NCH{}, t);
     };
     int t = 0;
     for (; t + 1 < nt; t += 2) {
@@ -1188,7 +1282,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int ln = lane;
     asm volatile("" : "+v"(ln));                                 // the row pointers are formed here, not kept in registers across the tile loop
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
         const int k0 = kbase0 + kb * 32;
         if (k0 < N) {
             // the Q rows in memory are Q * scale * log2(e): dK = dS^T Q * scale = acc * ln 2
@@ -1233,6 +1327,21 @@ static int attention_bwd_t(const void* qkv, int ldqkv, const void* o, const void
 
 using namespace pa;
 
+// 1 = attribute set on this device, -1 = refused (per device, decided on the device's first call; a benign race between two
+// host threads setting the same attribute twice)
+static bool fused_lds_ok() {
+    static signed char state[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (e != hipSuccess || e2 != hipSuccess) (void)hipGetLastError();
+        state[dev] = (e == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+    }
+    return state[dev] > 0;
+}
+
 static bool attn_args_ok(int ld, int dtype) {
     const int es = dtype == PA_BF16 ? 2 : 4;
     return (ld * es) % 16 == 0;
@@ -1253,7 +1362,7 @@ extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const
                                 const float* lse, float* delta, void* dqkv, int lddqkv, int B, int H, int N, int nq,
                                 float scale, int dtype, int flags, void* stream) {
     if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || H <= 0 || N <= 0 || nq <= 0 || nq > N ||
-        (flags & ~(PA_ATTN_Q_PRESCALED | PA_ATTN_BWD_TWO_PASS | PA_ATTN_BWD_SINGLE_PASS)))
+        (flags & ~(PA_ATTN_Q_PRESCALED | PA_ATTN_BWD_TWO_PASS | PA_ATTN_BWD_SINGLE_PASS | PA_ATTN_BWD_SINGLE_PASS_W16)))
         return PA_EINVAL;
     if (!attn_args_ok(ldqkv, dtype) || !attn_args_ok(ldo, dtype) || !attn_args_ok(lddqkv, dtype)) return PA_EUNSUPPORTED;
     const bool pre = flags & PA_ATTN_Q_PRESCALED;
@@ -1261,12 +1370,18 @@ extern "C" int pa_attention_bwd(const void* qkv, int ldqkv, const void* o, const
     // single pass where it applies and fills the chip: one workgroup per (sequence, head) takes a whole CU (148 KiB of LDS), so B * H
     // below two rounds of 256 CUs leaves the two-kernel form (3-4 x as many, smaller workgroups) ahead -- ESC-50 at batch 12: 144
     const bool can_fuse = dtype == PA_BF16 && pre && nq == N && N <= FK;
-    if (can_fuse && !(flags & PA_ATTN_BWD_TWO_PASS) && ((flags & PA_ATTN_BWD_SINGLE_PASS) || (int64_t)B * H >= 512)) {
-        static const int attr_rc = (int)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-        if (attr_rc) return PA_ELAUNCH;
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)(B * H)), dim3(512), F_LDS, st, (const bf16*)qkv, ldqkv, (const bf16*)o,
-                           (const bf16*)d_o, ldo, lse, (bf16*)dqkv, lddqkv, H, N, scale);
-        return check_launch();
+    if (can_fuse && !(flags & PA_ATTN_BWD_TWO_PASS) && ((flags & (PA_ATTN_BWD_SINGLE_PASS | PA_ATTN_BWD_SINGLE_PASS_W16)) || (int64_t)B * H >= 512)) {
+        // the 148 KiB of dynamic LDS need the attribute on EVERY device this process drives (it is per device: keyed on
+        // hipGetDevice(), not set once for whichever device made the first call); a device that refuses it runs the two-kernel form
+        if (fused_lds_ok()) {
+            if (flags & PA_ATTN_BWD_SINGLE_PASS_W16)
+                hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3((unsigned)(B * H)), dim3(1024), F_LDS, st, (const bf16*)qkv, ldqkv, (const bf16*)o,
+                                   (const bf16*)d_o, ldo, lse, (bf16*)dqkv, lddqkv, H, N, scale);
+            else
+                hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3((unsigned)(B * H)), dim3(512), F_LDS, st, (const bf16*)qkv, ldqkv, (const bf16*)o,
+                                   (const bf16*)d_o, ldo, lse, (bf16*)dqkv, lddqkv, H, N, scale);
+            return check_launch();
+        }
     }
     if (dtype == PA_BF16)
         return pre ? attention_bwd_t<bf16, true>(qkv, ldqkv, o, d_o, ldo, lse, delta, dqkv, lddqkv, B, H, N, nq, scale, st)

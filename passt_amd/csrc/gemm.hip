@@ -863,8 +863,11 @@ template <int KBT> __device__ __forceinline__ int swz_rows(int row) {
     else return (row >> 2) & 3;
 }
 
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(KBT == 64 ? 2 : 1))) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+// BLK (r06): the epilogue is the role-split kernels' v2 epilogue (accumulator-layout math, packed row-pair slab, buffer
+// instructions) with the MLP pre-activation in the library's blocked layout -- what makes the blocked pre-activation reachable
+// from the tiles that fit TWO workgroups per CU (tunes 3 / 9: one workgroup's transposition + store burst under the other's K loop)
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, bool BLK = false>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu((KBT == 64 || BLK) ? 2 : 1))) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                                const int nwg, const int ksteps_per_split) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
     constexpr int A_BYTES = TBM * KBT, B_BYTES = TBN * KBT, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -977,27 +980,41 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(KB
         }
         if (++buf == STAGES) buf = 0;
     }
-    __syncthreads();  // every wave is done reading the operand tiles; LDS is reused by the slabs
-    gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8, tm * WM + wr);
+    if constexpr (BLK) {
+        static_assert(sizeof(T) == 2 && (EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU), "blocked pre-activation: bf16 GELU / GELU' only");
+        V2Aux<EPI, TM, true> aux;
+        aux.issue(a, m0, n0, wr, wc, lane);          // GELU': the first pre-activation passes are in flight across the barrier
+        __syncthreads();                             // every wave is done reading the operand tiles; LDS is reused by the slabs
+        // (the bias row is read from global memory: N % 64 == 0 and the wave tile's early-out keep wc * 64 + c inside it)
+        gemm_epilogue_v2_bf16<EPI, TM, true>(a, acc, smem + wave * 8192, (EPI == PA_EPI_GELU && a.bias) ? a.bias + n0 : nullptr, m0, n0,
+                                             wr, wc, lane, tm * WM + wr, aux);
+    } else {
+        __syncthreads();  // every wave is done reading the operand tiles; LDS is reused by the slabs
+        gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8, tm * WM + wr);
+    }
 }
 
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB>
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, bool BLK = false>
 static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
     constexpr int LDS = STAGES * (TBM + TBN) * KBT;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static_assert(LDS >= WM * WN * 32 * 68 * 4, "epilogue slabs must fit");
+    if constexpr (BLK) {     // buffer-descriptor epilogue: every row within 2 GiB of the first one
+        const int64_t lim = (int64_t)1 << 31;
+        if ((int64_t)a.M * a.ldolp * 2 >= lim || (int64_t)a.M * a.ldolp2 * 2 >= lim) return PA_EUNSUPPORTED;
+    }
     const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, TBN);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KBT);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
     static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT>,
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, BLK>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, BLK>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
                        tiles_m, tiles_n, nwg, per);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * WM, st);
@@ -1446,6 +1463,9 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
                     case 8: return launch_gemm_stagger<T, EPI, 2, false, true>(a, st);
                     case 17: return launch_gemm_stagger<T, EPI, 3, true, true>(a, st);
                     case 18: return launch_gemm_stagger<T, EPI, 2, true, true>(a, st);
+                    // r06: the two-workgroups-per-CU tiles with the v2 epilogue (explicit tune only; profiles/r06_gemm_variants_epi13.txt)
+                    case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2, KB, true>(a, st);       // 192x128, 4 waves, 80 KiB
+                    case 9: return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64, true>(a, st);       // 128x256, 4 waves, 72 KiB
                 }
                 return PA_EUNSUPPORTED;
             }

@@ -78,6 +78,138 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
     for (int64_t i = n4 * 4 + t0; i < n; i += stride) adamw_one(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2_sqrt);
 }
 
+// ---- AdamW + weight staging in ONE pass (round 6).  The step used to end with adamw_kernel writing every updated parameter and
+// the next forward beginning with stage_weights_kernel reading all of them back to make the GEMM-ready copies (bf16 W[out][in]
+// for the forward, bf16 W^T[in][out] for the input gradients): one extra 345 MB read + a launch per step.  Here the optimizer
+// launch of a bucket walks a descriptor table of the bucket's parameters: a matrix with copies is processed in 64 x 64 tiles
+// (256 B of each row per 16 lanes; the updated values go out as f32, as the straight cast, and -- through an LDS tile -- as the
+// transposed cast), everything else in runs of 4096 elements.  Same adamw_one() as adamw_kernel: parameters, moments and both
+// copies are bit-identical to adamw_kernel + stage_weights_kernel (tests/test_gpu_model.py).
+struct AdamwHyper { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
+
+template <typename TO>
+__global__ __launch_bounds__(256) void adamw_stage_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const pa_adamw_stage_desc* __restrict__ descs,
+                                                          int n_desc, const float* __restrict__ hy_dev, AdamwHyper hv) {
+    __shared__ float tile[64][65];
+    __shared__ int s_entry;
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {                // one wave scans the (short) table: the last entry with tile_begin <= bid
+        int found = -1;
+        for (int e = tid; e < n_desc; e += 64)
+            if (descs[e].tile_begin <= bid) found = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, 64));
+        if (tid == 0) s_entry = found;
+    }
+    __syncthreads();
+    const pa_adamw_stage_desc d = descs[s_entry];
+    AdamwHyper h = hv;
+    if (hy_dev) { h.lr = hy_dev[0]; h.b1 = hy_dev[1]; h.b2 = hy_dev[2]; h.eps = hy_dev[3]; h.wd = hy_dev[4]; h.bc1 = hy_dev[5]; h.bc2_sqrt = hy_dev[6]; }
+    float* pp = p + d.offset;
+    const float* gp = g + d.offset;
+    float* mp = m + d.offset;
+    float* vp = v + d.offset;
+    const int t = bid - d.tile_begin;
+    const bool aligned = ((((uintptr_t)pp | (uintptr_t)gp | (uintptr_t)mp | (uintptr_t)vp) & 15) == 0);
+    if (!d.dst && !d.dst_t) {
+        // a parameter without copies (biases, LayerNorm, positional tables, the f32 head): a run of 4096 consecutive elements
+        const int64_t n = (int64_t)d.rows * d.cols, i0 = (int64_t)t * 4096, i1 = min(i0 + 4096, n);
+        if (aligned) {
+            for (int64_t i = i0 + tid * 4; i < i1; i += 1024) {
+                if (i + 4 <= i1) {
+                    f32x4 pv = *(f32x4*)(pp + i), mv = *(f32x4*)(mp + i), vv = *(f32x4*)(vp + i);
+                    const f32x4 gv = *(const f32x4*)(gp + i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = pv[e], me = mv[e], ve = vv[e];
+                        adamw_one(pe, gv[e], me, ve, h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
+                        pv[e] = pe; mv[e] = me; vv[e] = ve;
+                    }
+                    *(f32x4*)(pp + i) = pv; *(f32x4*)(mp + i) = mv; *(f32x4*)(vp + i) = vv;
+                } else {
+                    for (int64_t k = i; k < i1; ++k) adamw_one(pp[k], gp[k], mp[k], vp[k], h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
+                }
+            }
+        } else {
+            for (int64_t i = i0 + tid; i < i1; i += 256) adamw_one(pp[i], gp[i], mp[i], vp[i], h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
+        }
+        return;
+    }
+    const int tiles_c = (d.cols + 63) >> 6;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    TO* dst = (TO*)d.dst;
+    TO* dst_t = (TO*)d.dst_t;
+    if (((d.rows | d.cols) & 3) == 0 && aligned) {
+        // every PaSST weight: 16-byte accesses, 256 contiguous bytes of a row per 16 lanes
+        const int lr = tid >> 4, l4 = (tid & 15) * 4;
+        // all sixteen loads of the thread's four row pieces first (the stores below would otherwise fence the next piece's loads:
+        // the four pointers alias as far as the compiler knows), then the arithmetic and the stores
+        f32x4 pv[4], mv[4], vv[4], gv[4];
+        bool in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + lr + 16 * i, c = c0 + l4;
+            in[i] = r < d.rows && c < d.cols;
+            const int64_t at = in[i] ? (int64_t)r * d.cols + c : 0;
+            pv[i] = *(const f32x4*)(pp + at); mv[i] = *(const f32x4*)(mp + at); vv[i] = *(const f32x4*)(vp + at); gv[i] = *(const f32x4*)(gp + at);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + lr + 16 * i, c = c0 + l4;
+            if (in[i]) {
+                const int64_t at = (int64_t)r * d.cols + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = pv[i][e], me = mv[i][e], ve = vv[i][e];
+                    adamw_one(pe, gv[i][e], me, ve, h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
+                    pv[i][e] = pe; mv[i][e] = me; vv[i][e] = ve;
+                }
+                *(f32x4*)(pp + at) = pv[i]; *(f32x4*)(mp + at) = mv[i]; *(f32x4*)(vp + at) = vv[i];
+                if (dst) {
+                    if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst + at) = bf16x4{(bf16)pv[i][0], (bf16)pv[i][1], (bf16)pv[i][2], (bf16)pv[i][3]};
+                    else *(f32x4*)(dst + at) = pv[i];
+                }
+            } else {
+                pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[lr + 16 * i][l4 + k] = pv[i][k];
+        }
+        if (!dst_t) return;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + lr + 16 * i, r = r0 + l4;
+            if (c < d.cols && r < d.rows) {
+                const f32x4 w = {tile[l4][lr + 16 * i], tile[l4 + 1][lr + 16 * i], tile[l4 + 2][lr + 16 * i], tile[l4 + 3][lr + 16 * i]};
+                if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst_t + (int64_t)c * d.rows + r) = bf16x4{(bf16)w[0], (bf16)w[1], (bf16)w[2], (bf16)w[3]};
+                else *(f32x4*)(dst_t + (int64_t)c * d.rows + r) = w;
+            }
+        }
+        return;
+    }
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        const bool ok = r < d.rows && c < d.cols;
+        float w = 0.f;
+        if (ok) {
+            const int64_t at = (int64_t)r * d.cols + c;
+            adamw_one(pp[at], gp[at], mp[at], vp[at], h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
+            w = pp[at];
+            if (dst) dst[at] = from_f32<TO>(w);
+        }
+        tile[i][tx] = w;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < d.cols && r < d.rows) dst_t[(int64_t)c * d.rows + r] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] -= lr * g[i];
@@ -173,6 +305,23 @@ extern "C" int pa_adamw_dev(float* p, const float* g, float* m, float* v, int64_
     const int64_t n4 = vec ? n / 4 : 0;
     const int blocks = (int)std::min<int64_t>(cdiv(std::max<int64_t>(n4, 1), 256), 8192);
     hipLaunchKernelGGL(adamw_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, hyper);
+    return check_launch();
+}
+
+extern "C" int pa_adamw_stage(float* p, const float* g, float* m, float* v, const pa_adamw_stage_desc* descs, int n_desc,
+                              int total_items, int dtype, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              const float* hyper_dev, void* stream) {
+    if (!p || !g || !m || !v || !descs || n_desc < 1 || total_items < 1 || (!hyper_dev && step < 1)) return PA_EINVAL;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    AdamwHyper h{lr, beta1, beta2, eps, weight_decay, 1.f, 1.f};
+    if (!hyper_dev) {
+        h.bc1 = 1.f - powf(beta1, (float)step);
+        h.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    }
+    if (dtype == PA_BF16)
+        hipLaunchKernelGGL(adamw_stage_kernel<bf16>, dim3(total_items), dim3(256), 0, (hipStream_t)stream, p, g, m, v, descs, n_desc, hyper_dev, h);
+    else
+        hipLaunchKernelGGL(adamw_stage_kernel<float>, dim3(total_items), dim3(256), 0, (hipStream_t)stream, p, g, m, v, descs, n_desc, hyper_dev, h);
     return check_launch();
 }
 

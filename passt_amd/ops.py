@@ -221,6 +221,27 @@ def make_stage_table(entries, device):
     return host.to(device), len(entries), tiles
 
 
+def make_adamw_stage_table(entries, device):
+    """entries: [(offset, rows, cols, dst or None, dst_t or None)] in flat-buffer order -> (device table, n, total work items) for
+    adamw_stage (pa_adamw_stage_desc; a parameter without copies is one run of 4096 elements per work item)."""
+    import numpy as np
+    from ._lib import AdamwStageDesc
+    arr = (AdamwStageDesc * len(entries))()
+    items = 0
+    for d, (off, rows, cols, dst, dst_t) in zip(arr, entries):
+        d.offset, d.rows, d.cols, d.dst, d.dst_t, d.tile_begin = off, rows, cols, _p(dst), _p(dst_t), items
+        items += ((rows + 63) // 64) * ((cols + 63) // 64) if (dst is not None or dst_t is not None) else (rows * cols + 4095) // 4096
+    host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+    return host.to(device), len(entries), items
+
+
+def adamw_stage(p, g, m, v, table, n, items, dtype, lr, beta1, beta2, eps, weight_decay, step, hyper_dev=None):
+    """AdamW over the parameters the table lists (offsets relative to p / g / m / v) + their GEMM-ready copies, one launch."""
+    check(_lib.load().pa_adamw_stage(_p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32), _p(table), n, items,
+                                     dtype, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                     _p(hyper_dev), _stream()), "pa_adamw_stage")
+
+
 def stage_weights(table, n, tiles, dtype):
     check(_lib.load().pa_stage_weights(_p(table), n, tiles, dtype, _stream()), "pa_stage_weights")
 
@@ -264,7 +285,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
 # ---- GEMM ------------------------------------------------------------------------------------
 def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
             out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None,
-            colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0, colscale_n=0, colscale=1.0):
+            colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0, colscale_n=0, colscale=1.0, tune=None):
     """C[M][N] = A[M][K] B[N][K]^T with the fused epilogues of include/passt_amd.h.  EPI_DGELU can also return the
     column sums of its output (colsum_out [N] f32; colsum_ws from gemm_colsum_ws)."""
     a = GemmArgs()
@@ -287,7 +308,7 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.out_lp2 = _p(out_lp2, dtype, True)
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
-    a.tune = GEMM_TUNE
+    a.tune = GEMM_TUNE if tune is None else tune
     a.reserved = GEMM_RESERVED | _call.gemm_flags | flags
     a.colscale_n, a.colscale = colscale_n, colscale
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
@@ -369,6 +390,12 @@ def blocked_pre_ok(M, N, K):
     return not GEMM_TUNE and not os.environ.get("PASST_AMD_NO_BLOCKED_PRE") and _lib_blocked_pre_ok(M, N, K)
 
 
+# A/B knobs (tools/bench_epi13.py, profiles/r06_gemm_variants_epi13.txt): the tile variant of the two MLP-epilogue GEMMs in the
+# step, blocked pre-activation kept (every variant listed in csrc/gemm.hip launch_gemm's blocked switch has it)
+TUNE_GELU = int(os.environ.get("PASST_AMD_TUNE_GELU", "0")) or None
+TUNE_DGELU = int(os.environ.get("PASST_AMD_TUNE_DGELU", "0")) or None
+
+
 def linear_gelu(x_lp, W_lp, bias, dtype):
     """(pre, act): act = gelu(x W^T + b) row-major; pre = x W^T + b, row-major or -- where the library has the blocked
     form for this shape -- a BlockedPre that only dgelu_gemm() can consume."""
@@ -379,7 +406,7 @@ def linear_gelu(x_lp, W_lp, bias, dtype):
         # blocks of rows no wave tile of this GEMM writes: the GELU' epilogue of the last row tile adds and subtracts them
         # for the fused bias sums, so they must be finite whatever tile height the two GEMMs resolve to
         buf[(M + 31) // 32 * 32 * N:].zero_()
-        gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=buf.view(-1, N), out_lp2=act, flags=GEMM_BLOCKED_PRE)
+        gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=buf.view(-1, N), out_lp2=act, flags=GEMM_BLOCKED_PRE, tune=TUNE_GELU)
         return BlockedPre(buf, (M, N)), act
     pre = torch.empty((M, N), device=x_lp.device, dtype=TORCH_DTYPE[dtype])
     gemm_nt(x_lp, W_lp, dtype, EPI_GELU, bias=bias, out_lp=pre, out_lp2=act)
@@ -395,7 +422,8 @@ def dgelu_gemm(dy_lp, Wt_lp, pre, dtype, colsum_out=None, colsum_ws=None, defer=
     d_pre = torch.empty((M, N), device=dy_lp.device, dtype=TORCH_DTYPE[dtype])
     deferred = defer is not None and colsum_out is not None
     gemm_nt(dy_lp, Wt_lp, dtype, EPI_DGELU, aux=pre.buf.view(-1, N) if blocked else pre, out_lp=d_pre,
-            colsum_out=colsum_out, colsum_ws=colsum_ws, flags=(GEMM_BLOCKED_PRE if blocked else 0) | (_lib.GEMM_COLSUM_DEFER if deferred else 0))
+            colsum_out=colsum_out, colsum_ws=colsum_ws, flags=(GEMM_BLOCKED_PRE if blocked else 0) | (_lib.GEMM_COLSUM_DEFER if deferred else 0),
+            tune=TUNE_DGELU if blocked else None)
     if deferred:
         defer.append((colsum_ws, _lib.load().pa_gemm_last_colsum_rows(), N, N, colsum_out))
     return d_pre
@@ -622,7 +650,9 @@ def colsum_f32(x, out_f32, accumulate=False):
 ATTN_Q_PRESCALED = 1          # include/passt_amd.h PA_ATTN_Q_PRESCALED
 ATTN_BWD_TWO_PASS = 2         # PA_ATTN_BWD_TWO_PASS: force the dQ + dK/dV kernel pair (A/B, tests); PASST_AMD_ATTN_BWD=two_pass sets it everywhere
 ATTN_BWD_SINGLE_PASS = 4      # PA_ATTN_BWD_SINGLE_PASS: force the single-pass kernel wherever it applies; PASST_AMD_ATTN_BWD=single_pass
-_ATTN_BWD_FORCE = {"two_pass": ATTN_BWD_TWO_PASS, "single_pass": ATTN_BWD_SINGLE_PASS}.get(os.environ.get("PASST_AMD_ATTN_BWD", ""), 0)
+ATTN_BWD_SINGLE_PASS_W16 = 8  # PA_ATTN_BWD_SINGLE_PASS_W16 (ABI 6): the single pass as sixteen waves of 32 keys; PASST_AMD_ATTN_BWD=single_pass_w16
+_ATTN_BWD_FORCE = {"two_pass": ATTN_BWD_TWO_PASS, "single_pass": ATTN_BWD_SINGLE_PASS,
+                   "single_pass_w16": ATTN_BWD_SINGLE_PASS_W16}.get(os.environ.get("PASST_AMD_ATTN_BWD", ""), 0)
 LOG2E = 1.4426950408889634
 
 

@@ -156,6 +156,8 @@ class _Staged:
         self.cache = {}     # (id(p), dtype, transposed) -> [version, tensor, p]
         self.tables = {}    # dtype -> (signature, device table, n, tiles, keys)
         self.epoch = 0      # bumped by optimizers that update parameters through raw pointers
+        self.gen = 0        # bumped whenever a copy tensor is created: fused optimizer tables (adamw_table) are keyed on it
+        self.fused = {}     # (span key, dtype) -> (gen, device table, n, items, cache keys covered)
 
     def _version(self, p):
         return (p._version, p.data_ptr(), self.epoch)
@@ -206,7 +208,40 @@ class _Staged:
             out = ops.convert(w2, dtype)
         self.cache[key] = [ver, out, p]
         self.tables.pop(dtype, None)
+        self.gen += 1
         return out
+
+    def adamw_table(self, span_key, params, dtype):
+        """The pa_adamw_stage descriptor table of one optimizer launch: ``params`` = [(parameter, element offset in the launch's
+        flat buffers)], every parameter of the launch in buffer order.  A parameter with GEMM-ready copies of ``dtype`` in the
+        cache gets them rewritten by the optimizer launch itself (no separate pa_stage_weights pass reads the updated values
+        back); returns (device table, n, work items, covered cache keys) -- mark_fresh(keys) once the parameters' epoch was bumped."""
+        hit = self.fused.get((span_key, dtype))
+        if hit is not None and hit[0] == self.gen:
+            return hit[1:]
+        entries, keys = [], []
+        for p, off in params:
+            kd, kt = (id(p), dtype, False), (id(p), dtype, True)
+            d, t = self.cache.get(kd), self.cache.get(kt)
+            ok = (d is not None or t is not None) and p.dim() >= 2 and p.is_contiguous()
+            if ok and d is not None and d[2] is not p or ok and t is not None and t[2] is not p:
+                ok = False                                      # an id re-used by another tensor: leave it to get()
+            if not ok:
+                entries.append((off, 1, p.numel(), None, None))
+                continue
+            rows = p.shape[0]
+            entries.append((off, rows, p.numel() // rows, None if d is None else d[1], None if t is None else t[1]))
+            keys += [k for k, e in ((kd, d), (kt, t)) if e is not None]
+        tab = ops.make_adamw_stage_table(entries, params[0][0].device)
+        self.fused[(span_key, dtype)] = (self.gen,) + tab + (keys,)
+        return tab + (keys,)
+
+    def mark_fresh(self, keys):
+        """The copies under ``keys`` were just rewritten from the current parameter values (fused optimizer launch)."""
+        for k in keys:
+            ent = self.cache.get(k)
+            if ent is not None:
+                ent[0] = self._version(ent[2])
 
 
 def _prefix_rows(model, B, Ntok, device):

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .ddp import GradReducer
-from .passt import passt_backward, passt_forward, patchout_draws
+from .passt import _precision, passt_backward, passt_forward, patchout_draws
 
 
 class TrainStep:
@@ -72,6 +72,16 @@ class TrainStep:
         self.t = self._t_now = 0
         self.block_optimizer = os.environ.get("PASST_AMD_BLOCK_OPT", "1") != "0"      # one GPU: per-bucket updates from the backward
         self.base_lr = lr
+        # AdamW and the GEMM-ready weight copies in one launch per bucket (pa_adamw_stage, round 6): the copies the next forward
+        # needs are written from the registers that hold the updated parameters; PASST_AMD_NO_FUSED_STAGE=1: A/B, the optimizer
+        # leaves them stale and the next forward's first GEMM refreshes all of them with one pa_stage_weights launch
+        self.fused_stage = optimizer == "adamw" and os.environ.get("PASST_AMD_NO_FUSED_STAGE") != "1"
+        self._offsets = []
+        off = 0
+        for _, p in self.named:
+            self._offsets.append(off)
+            off += p.numel()
+        self._fresh = []
         net.mark_params_updated()
 
     def _optimizer(self, s, e):
@@ -80,11 +90,35 @@ class TrainStep:
             if self.optimizer != "adamw":
                 raise NotImplementedError("graph mode: AdamW only")
             return ops.adamw_dev(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self._g["hyper"])
-        if self.optimizer == "adamw":
+        if self.optimizer == "adamw" and self.fused_stage:
+            # no kernel enqueued after this point reads this bucket's copies before the next forward: the bucket's own input-
+            # gradient GEMMs (the readers of W^T) are already on the stream, earlier blocks read their own weights
+            st, dt = self.net._staged, _precision(self.net)
+            lo, hi = self._span_params(s, e)
+            tab, n, items, keys = st.adamw_table((s, e), [(self.named[i][1], self._offsets[i] - s) for i in range(lo, hi)], dt)
+            ops.adamw_stage(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], tab, n, items, dt, self.lr, self.betas[0],
+                            self.betas[1], self.eps, self.wd, self._t_now)
+            self._fresh += keys
+        elif self.optimizer == "adamw":
             ops.adamw(self.flat_p[s:e], self.flat_g[s:e], self.m[s:e], self.v[s:e], self.lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, self._t_now)
         else:
             ops.sgd(self.flat_p[s:e], self.flat_g[s:e], self.lr)
+
+    def _span_params(self, s, e):
+        """indices [lo, hi) into self.named of the parameters that make up flat span [s, e) (spans are unions of whole parameters)"""
+        import bisect
+        lo, hi = bisect.bisect_left(self._offsets, s), bisect.bisect_left(self._offsets, e)
+        assert self._offsets[lo] == s and (hi == len(self._offsets) or self._offsets[hi] == e)
+        return lo, hi
+
+    def _params_updated(self):
+        """End of a step: every parameter changed (epoch bump: all staged copies stale) -- except that the copies the fused
+        optimizer launches of this step rewrote are current."""
+        self.net.mark_params_updated()
+        if self._fresh:
+            self.net._staged.mark_fresh(self._fresh)
+            self._fresh = []
 
     def _block_done(self, i):
         """Called by the backward on its finishing stream once bucket i's gradients are complete (head, blocks depth-1 .. 0,
@@ -191,7 +225,7 @@ class TrainStep:
             for s_, e_ in self.reducer.drain():
                 self._optimizer(s_, e_)
         self.t = self._t_now
-        net.mark_params_updated()
+        self._params_updated()
         return loss
 
     def _graph_fits(self, x):

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in passt_amd/_lib.py"
         assert hasattr(lib, n), f"{n} not exported by libpasst_amd.so"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.pa_abi_version() == 5
+    assert lib.pa_abi_version() == 6
     assert lib.pa_error_string(-2) == b"unsupported shape or dtype"
     assert lib.pa_mel_num_frames(320000, 320) == 1000          # 10 s -> 1000 frames
     assert lib.pa_layernorm_bwd_ws_floats(30336, 768) == 1024 * 3 * 768 and lib.pa_layernorm_bwd_rows(30336) == 1024
@@ -46,11 +46,12 @@ def test_ctypes_structs_match_the_c_layout():
 #include <stddef.h>
 #include "passt_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pa_gemm_args), offsetof(pa_gemm_args, A), offsetof(pa_gemm_args, resid),
          offsetof(pa_gemm_args, aux), offsetof(pa_gemm_args, out_f32), offsetof(pa_gemm_args, out_lp2),
          offsetof(pa_gemm_args, tune), sizeof(pa_mel_params), offsetof(pa_gemm_args, colsum_out),
          offsetof(pa_gemm_args, colsum_accumulate), sizeof(pa_stage_desc), offsetof(pa_gemm_args, colscale_n),
-         offsetof(pa_gemm_args, colscale), sizeof(pa_reduce_desc), offsetof(pa_reduce_desc, pitch), offsetof(pa_reduce_desc, mode));
+         offsetof(pa_gemm_args, colscale), sizeof(pa_reduce_desc), offsetof(pa_reduce_desc, pitch), offsetof(pa_reduce_desc, mode),
+         sizeof(pa_adamw_stage_desc), offsetof(pa_adamw_stage_desc, dst_t), offsetof(pa_adamw_stage_desc, tile_begin));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -61,7 +62,8 @@ int main(void) {
     got = [ctypes.sizeof(G), G.A.offset, G.resid.offset, G.aux.offset, G.out_f32.offset, G.out_lp2.offset,
            G.tune.offset, ctypes.sizeof(_lib.MelParams), G.colsum_out.offset, G.colsum_accumulate.offset,
            ctypes.sizeof(_lib.StageDesc), G.colscale_n.offset, G.colscale.offset, ctypes.sizeof(_lib.ReduceDesc),
-           _lib.ReduceDesc.pitch.offset, _lib.ReduceDesc.mode.offset]
+           _lib.ReduceDesc.pitch.offset, _lib.ReduceDesc.mode.offset, ctypes.sizeof(_lib.AdamwStageDesc),
+           _lib.AdamwStageDesc.dst_t.offset, _lib.AdamwStageDesc.tile_begin.offset]
     assert got == [int(v) for v in out]
 
 

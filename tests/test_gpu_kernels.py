@@ -351,8 +351,9 @@ def _attn_ref(qkv, B, H, N, scale, d_o=None):
 
 
 # `pre`: 0 = plain, 1 = PA_ATTN_Q_PRESCALED (backward: the library's choice), 3 = pre-scaled + PA_ATTN_BWD_TWO_PASS (the dQ + dK/dV
-# kernel pair), 5 = pre-scaled + PA_ATTN_BWD_SINGLE_PASS (the single-pass kernel: bf16, N <= 512; ignored elsewhere)
-@pytest.mark.parametrize("pre", [0, 1, 3, 5])
+# kernel pair), 5 = pre-scaled + PA_ATTN_BWD_SINGLE_PASS (the single-pass kernel: bf16, N <= 512; ignored elsewhere), 9 = pre-scaled +
+# PA_ATTN_BWD_SINGLE_PASS_W16 (round 6: the single pass as sixteen waves of 32 keys)
+@pytest.mark.parametrize("pre", [0, 1, 3, 5, 9])
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
 @pytest.mark.parametrize("B,H,N", [(2, 2, 67), (1, 3, 474), (2, 12, 130), (1, 2, 1190), (3, 2, 64), (1, 1, 20),
                                    (1, 2, 512), (2, 1, 500), (1, 1, 33), (1, 2, 96), (2, 2, 353)])
@@ -381,7 +382,7 @@ def test_attention_fwd_bwd(dt, B, H, N, pre):
     assert e_q < lim and e_k < lim and e_v < lim, (e_q, e_k, e_v)
 
 
-@pytest.mark.parametrize("pre", [0, 1, 3, 5])
+@pytest.mark.parametrize("pre", [0, 1, 3, 5, 9])
 @pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
 @pytest.mark.parametrize("case", ["rising", "falling", "spikes", "large", "tiny"])
 def test_attention_running_max_paths(dt, case, pre):
@@ -428,7 +429,34 @@ def test_attention_running_max_paths(dt, case, pre):
     assert e_q < lim and e_k < lim and e_v < lim, (e_q, e_k, e_v)
 
 
-@pytest.mark.parametrize("pre", [0, 1, 3, 5])
+@pytest.mark.parametrize("pre", [1, 3, 5, 9])
+@pytest.mark.parametrize("N", [3, 20, 45, 70])
+def test_attention_bwd_strongly_negative_scores_with_keys_past_n(N, pre):
+    """in the single-pass backward the key lanes past N inside a live 32-key block see a zero K row, i.e. the score
+    exp2(-lse * log2 e); with every logit strongly negative (scores ~ -128: lse < -88) that is
+    inf, and inf in the transposition buffer times the zero K rows of phase 2 would be NaN in dQ of valid queries.  Those lanes no
+    longer write T.  Every backward form, against the fp64 reference, finite everywhere."""
+    B, H = 2, 2
+    D = H * 64
+    # keys = 4 in every coordinate + noise, queries = -4 + noise: every score ~ (-64 * 16 +- 50) / 8 = -128 +- 6 (the noise keeps
+    # dQ = sum_k dS[k] K[k], with sum_k dS[k] = 0, well conditioned against the bf16 rounding of dS)
+    x = rnd(B * N, 3 * D, seed=77, scale=1.5)
+    x[:, D:2 * D] += 4.0
+    x[:, :D] -= 4.0
+    qkv, qref = _attn_inputs(x, PA_BF16, D, 1)
+    o, lse = ops.attention_fwd(qkv, B, H, N, 0.125, flags=1)
+    assert float(lse.max()) < -100.0
+    d_o = rnd(B * N, D, seed=78).to(torch.bfloat16).to(DEV)
+    ro, rlse, rdqkv = _attn_ref(qref, B, H, N, 0.125, d_o)
+    dqkv = ops.attention_bwd(qkv, o, d_o, lse, B, H, N, 0.125, flags=pre)
+    assert torch.isfinite(dqkv.float()).all()
+    Dq = dqkv.double().cpu()
+    e_q, e_k, e_v = (rel_err(Dq[:, :D], rdqkv[:, :D]), rel_err(Dq[:, D:2 * D], rdqkv[:, D:2 * D]),
+                     rel_err(Dq[:, 2 * D:], rdqkv[:, 2 * D:]))
+    assert e_q < 5e-2 and e_k < 5e-2 and e_v < 5e-2, (e_q, e_k, e_v)
+
+
+@pytest.mark.parametrize("pre", [0, 1, 3, 5, 9])
 def test_attention_bit_deterministic_at_bench_shape(pre):
     """B = 64, H = 12, N = 474 (BASELINE config #2), bf16: four launches on the same input are bit-identical and finite, and
     eight sampled (clip, head) pairs of the full launch match the fp64 reference in value (forward and backward).  The
@@ -694,6 +722,63 @@ def test_stage_weights_batched(dt):
             assert torch.equal(dst, w.to(TD[dt]))
         if dst_t is not None:
             assert torch.equal(dst_t, w.t().contiguous().to(TD[dt]))
+
+
+@pytest.mark.parametrize("dt", [PA_F32, PA_BF16])
+@pytest.mark.parametrize("hyper_on_device", [False, True])
+def test_adamw_stage_equals_adamw_then_stage_weights(dt, hyper_on_device):
+    """ABI 6: pa_adamw_stage (optimizer update + straight / transposed copies from the registers that hold the updated values) is
+    bit-identical -- parameters, both moments, every copy -- to pa_adamw followed by pa_stage_weights, over matrices with both /
+    one / no copy, shapes off the 64-tile and off the 4-element grid, a parameter at an odd (unaligned) offset, and with the
+    step's scalars by value or in device memory."""
+    shapes = [(768, 768), (768,), (2304, 768), (70, 130), (64, 64), (3, 5), (527,), (527, 768), (5000,), (768, 256)]
+    copies = ["both", None, "both", "both", "t", "both", None, None, None, "straight"]       # (3, 5) and what follows sit at odd offsets
+    offs, off = [], 0
+    for sh in shapes:
+        offs.append(off)
+        off += int(np.prod(sh))
+    total = off
+    g0 = torch.Generator().manual_seed(5)
+    P = (torch.rand(total, generator=g0) * 2 - 1).to(DEV)
+    G = ((torch.rand(total, generator=g0) * 2 - 1) * 1e-2).to(DEV)
+    Mo = ((torch.rand(total, generator=g0) * 2 - 1) * 1e-2).to(DEV)
+    Vo = (torch.rand(total, generator=g0) * 1e-4).to(DEV)
+    hp = dict(lr=3e-3, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2, step=7)
+    # (a) separately
+    pa, ma, va = P.clone(), Mo.clone(), Vo.clone()
+    ops.adamw(pa, G, ma, va, hp["lr"], hp["b1"], hp["b2"], hp["eps"], hp["wd"], hp["step"])
+    want = []
+    for sh, o, c in zip(shapes, offs, copies):
+        w = pa[o:o + int(np.prod(sh))].view(sh[0], -1) if c else None
+        want.append((None if c in (None, "t") else w.to(TD[dt]), None if c in (None, "straight") else w.t().contiguous().to(TD[dt])))
+    # (b) one launch
+    pb, mb, vb = P.clone(), Mo.clone(), Vo.clone()
+    entries, outs = [], []
+    for sh, o, c in zip(shapes, offs, copies):
+        rows = sh[0] if c else 1
+        cols = int(np.prod(sh)) // rows
+        dst = torch.full((rows, cols), 7.0, device=DEV, dtype=TD[dt]) if c in ("both", "straight") else None
+        dst_t = torch.full((cols, rows), 7.0, device=DEV, dtype=TD[dt]) if c in ("both", "t") else None
+        entries.append((o, rows, cols, dst, dst_t))
+        outs.append((dst, dst_t))
+    table, n, items = ops.make_adamw_stage_table(entries, DEV)
+    hy = None
+    if hyper_on_device:
+        host = torch.empty(7, dtype=torch.float32)
+        ops.adamw_hyper(hp["lr"], hp["b1"], hp["b2"], hp["eps"], hp["wd"], hp["step"], host)
+        hy = host.to(DEV)
+        ops.adamw_stage(pb, G, mb, vb, table, n, items, dt, 0.0, 0.0, 0.0, 0.0, 0.0, 0, hyper_dev=hy)
+    else:
+        ops.adamw_stage(pb, G, mb, vb, table, n, items, dt, hp["lr"], hp["b1"], hp["b2"], hp["eps"], hp["wd"], hp["step"])
+    torch.cuda.synchronize()
+    assert torch.equal(pb, pa) and torch.equal(mb, ma) and torch.equal(vb, va)
+    assert float((pb - P).abs().max()) > 1e-3
+    for (d, t), (wd_, wt_) in zip(outs, want):
+        assert (d is None) == (wd_ is None) and (t is None) == (wt_ is None)
+        if d is not None:
+            assert torch.equal(d, wd_)
+        if t is not None:
+            assert torch.equal(t, wt_)
 
 
 def test_staged_cache_batched_refresh_matches_single():

@@ -577,6 +577,55 @@ def test_optim_adamw_matches_torch():
     assert sorted(o1.state_dict()["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_train_step_fused_optimizer_staging_equals_separate(precision):
+    """Round 6: TrainStep's per-bucket AdamW launch also writes the GEMM-ready weight copies (pa_adamw_stage) instead of leaving
+    them to a pa_stage_weights pass at the start of the next forward.  Against PASST_AMD_NO_FUSED_STAGE=1 on the same draws over
+    three steps: losses, parameters, both moments bit-identical; every cached copy equal to the cast (transposed cast) of its
+    parameter and marked current, so the next forward launches no staging kernel."""
+    from passt_amd.train import TrainStep
+    case = dict(G.CASES["model_small_train"], seed=911)
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    runs = []
+    for knob in ("1", None):
+        if knob:
+            os.environ["PASST_AMD_NO_FUSED_STAGE"] = knob
+        else:
+            os.environ.pop("PASST_AMD_NO_FUSED_STAGE", None)
+        try:
+            net = build(case, precision).train()
+            ts = TrainStep(net, None, lr=1e-2, weight_decay=1e-2, use_mixup=False)
+            assert ts.fused_stage == (knob is None)
+            losses = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for i in range(3):
+                    torch.manual_seed(40 + i)
+                    losses.append(float(ts.step(xg, yg).item()))
+            runs.append((net, ts, losses))
+        finally:
+            os.environ.pop("PASST_AMD_NO_FUSED_STAGE", None)
+    (net_s, ts_s, l_s), (net_f, ts_f, l_f) = runs
+    assert l_s == l_f
+    assert torch.equal(ts_s.flat_p, ts_f.flat_p) and torch.equal(ts_s.m, ts_f.m) and torch.equal(ts_s.v, ts_f.v)
+    st = net_f._staged
+    td = torch.bfloat16 if precision == "bf16" else torch.float32
+    assert st.cache, "no staged copies?"
+    n_checked = 0
+    for (pid, dt, transposed), (ver, out, p) in st.cache.items():
+        assert ver == st._version(p), "a copy the fused optimizer rewrote is still marked stale"
+        w = p.detach().reshape(p.shape[0], -1)
+        assert torch.equal(out, (w.t().contiguous() if transposed else w).to(td))
+        n_checked += 1
+    assert n_checked >= 4 * len(net_f.blocks)
+    # ... and the separate path's copies ARE stale until its next forward refreshes them
+    st_s = net_s._staged
+    assert any(ver != st_s._version(p) for (ver, out, p) in st_s.cache.values())
+    ts_s.close()
+    ts_f.close()
+
+
 def test_swa_matches_reference_update_rule():
     """schedule.SWA (one fused kernel on the flat buffer) == helpers/swa_callback.py:246-268 applied per tensor
     (restated here: avg = p for the first snapshot, then avg + (p - avg) / (n + 1)); copy_to() loads a deepcopy."""
