@@ -481,6 +481,7 @@ def pick_split_k_slots(tiles, steps, slots=256):
 
 
 _SPLITS_CACHE = {}
+_FORCE_SLICES = int(os.environ.get("PASST_AMD_WGRAD_SLICES", "0"))
 
 
 def pick_batched_splits(probs, slots=256):
@@ -490,6 +491,8 @@ def pick_batched_splits(probs, slots=256):
     hit = _SPLITS_CACHE.get(key)
     if hit is None:
         hit = _SPLITS_CACHE[key] = _pick_batched_splits(list(probs), slots)
+        if _FORCE_SLICES:       # A/B knob (profiles/r06_wgrad_slices.txt): every problem cut into this many token slices
+            hit = _SPLITS_CACHE[key] = [max(1, min(_FORCE_SLICES, st)) for _, st in probs]
     return hit
 
 

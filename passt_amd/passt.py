@@ -290,6 +290,7 @@ def _passt_forward(model, x, save, draws=None):
     if not x.is_cuda:
         raise PasstAmdError("passt_amd.PaSST runs on a HIP device only (no CPU fallback); got a CPU tensor")
     dt = _precision(model)
+    object.__setattr__(model, "_last_dt", dt)       # the copies a bound optimizer refreshes (it steps outside torch.autocast)
     st = model._staged
     x = x.contiguous().float()
     if x.dim() != 4 or x.shape[1] != 1:
@@ -527,6 +528,9 @@ class _PasstFunction(torch.autograd.Function):
         logits, feat, c = passt_forward(model, x, save=True)
         ctx.model, ctx.c = model, c
         ctx.named, ctx.total = model._graph_params(validate=False)     # the list forward() just handed to apply()
+        # bound to a passt_amd.optim.AdamW (PaSST.bind_flat_grads): the only input is a token; the backward writes the gradients
+        # straight into the optimizer's persistent flat buffer -- p.grad are views of it -- and hands autograd nothing
+        ctx.flat = model._flat if (len(params) == 1 and model._flat is not None and params[0] is model._flat["token"]) else None
         ctx.set_materialize_grads(False)        # an unused `features` output arrives as None, not as a zero tensor
         return logits, feat
 
@@ -539,11 +543,15 @@ class _PasstFunction(torch.autograd.Function):
         # gradient buffers for EVERY parameter the backward writes (all but head_dist.*): the kernel sequence produces
         # them all; parameters with requires_grad=False are simply not handed back to autograd (frozen backbone, ...)
         named, total = ctx.named, ctx.total
-        flat = torch.empty(total, device=dlogits.device, dtype=torch.float32)
-        # one C++ call makes the 159 views (a Python loop of slice + view costs 1.3 ms of host time in front of the first
-        # backward kernel: exposed whenever the caller synchronised in this step, and the reference's mixup does)
-        views = torch._C._nn.unflatten_dense_tensors(flat, [p for _, p in named])
-        grads = {n: v for (n, _), v in zip(named, views)}
+        fl = ctx.flat
+        if fl is not None and fl["fresh"]:
+            flat, grads = fl["flat_g"], fl["grads"]     # overwritten in place: the caller zeroed (optimizer.zero_grad()) since the last backward
+        else:
+            flat = torch.empty(total, device=dlogits.device, dtype=torch.float32)
+            # one C++ call makes the 159 views (a Python loop of slice + view costs 1.3 ms of host time in front of the first
+            # backward kernel: exposed whenever the caller synchronised in this step, and the reference's mixup does)
+            views = torch._C._nn.unflatten_dense_tensors(flat, [p for _, p in named])
+            grads = {n: v for (n, _), v in zip(named, views)}
         # a fresh flat buffer per backward: autograd may keep (not copy) the views as .grad
         if dlogits is None:                     # only `features` fed the loss
             dlogits = torch.zeros((c["B"], model.num_classes), device=flat.device, dtype=torch.float32)
@@ -568,6 +576,11 @@ class _PasstFunction(torch.autograd.Function):
         else:
             passt_backward(model, c, dlogits, dfeat, grads)
         ctx.c = None
+        if fl is not None:
+            if not fl["fresh"]:                 # a second backward without zero_grad (gradient accumulation): add, as AccumulateGrad would
+                fl["flat_g"].add_(flat)
+            fl["fresh"] = False
+            return None, None, None
         out = [None, None]
         for n, p in named:                      # the same list, in the same order, as PaSST.forward handed to apply()
             out.append(grads[n] if p.requires_grad else None)
@@ -580,6 +593,12 @@ def _tree_signature(root):
     anywhere in ITS tree (net.head[1] = nn.Linear(768, 50), a block's sub-module replaced, a parameter re-registered) changes
     a tuple; nothing is hooked process-wide."""
     return [(m, tuple(map(id, m._parameters.values())), tuple(map(id, m._modules.values()))) for m in root.modules()]
+
+
+import weakref
+
+_LIVE = weakref.WeakSet()            # live PaSST instances: how passt_amd.optim.AdamW finds the model its parameters belong to
+_RUNTIME_ATTRS = ("_staged", "_scratch", "_ddp", "_gemm_flags", "_flat", "_last_dt")
 
 
 class PaSST(nn.Module):
@@ -634,6 +653,9 @@ class PaSST(nn.Module):
         object.__setattr__(self, "_scratch", {})
         object.__setattr__(self, "_ddp", None)          # passt_amd.ddp.attach(): gradient reducer of the autograd path
         object.__setattr__(self, "_gemm_flags", 0)      # pa_gemm_args.reserved bits of this model's GEMM launches
+        object.__setattr__(self, "_flat", None)         # bind_flat_grads(): flat gradient buffer owned by a passt_amd.optim.AdamW
+        object.__setattr__(self, "_last_dt", None)
+        _LIVE.add(self)
 
     def __deepcopy__(self, memo):
         cls = self.__class__
@@ -641,7 +663,7 @@ class PaSST(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_staged", "_scratch", "_ddp", "_gemm_flags"):
+            if k in _RUNTIME_ATTRS:
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._reset_runtime()
@@ -649,7 +671,7 @@ class PaSST(nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        for k in ("_staged", "_scratch", "_ddp", "_gemm_flags"):
+        for k in _RUNTIME_ATTRS:
             d.pop(k, None)
         return d
 
@@ -683,7 +705,41 @@ class PaSST(nn.Module):
         out = super()._apply(fn, *a, **k)
         if "_scratch" in self.__dict__:
             self._scratch.pop("graph_params", None)
+            self.unbind_flat_grads()            # .to() / .cuda() / .float() replaced the storages the flat views pointed into
         return out
+
+    # ---- one flat gradient for the drop-in path (FSDP use_orig_params-style) -------------------------------------
+    def bind_flat_grads(self, flat_g):
+        """Called by passt_amd.optim.AdamW once it owns this model's parameters as ONE flat buffer: ``flat_g`` (f32, numel = all
+        parameters the network produces gradients for, named_parameters() order without head_dist.*) becomes the model's
+        persistent gradient buffer.  From then on forward() hands autograd a single token instead of 159 parameters, the backward
+        writes every gradient straight into ``flat_g`` and ``p.grad`` of every parameter is a standing view of it: no
+        AccumulateGrad nodes, no per-parameter host work in backward / zero_grad / step -- what made the drop-in path host-bound at
+        ESC-50's batch of 12 (ex_esc50.py:40).  ``state_dict`` keys, ``parameters()`` order and the parameters themselves are
+        untouched.  Gradient semantics: after ``optimizer.zero_grad()`` (the bound optimizer marks the buffer fresh) a backward
+        overwrites; a further backward without zero_grad adds, like autograd.  Not for a torch DistributedDataParallel wrapper (its
+        reducer hooks AccumulateGrad; use passt_amd.ddp.attach, which reduces this buffer per block)."""
+        named, total = self._graph_params()
+        if any(not p.requires_grad for _, p in named):
+            return None                                  # frozen parameters: autograd decides which gradients exist; stay unbound
+        assert flat_g.numel() == total and flat_g.dtype == torch.float32
+        views = torch._C._nn.unflatten_dense_tensors(flat_g, [p for _, p in named])
+        for (n, p), v in zip(named, views):
+            p.grad = v
+        fl = dict(token=torch.zeros((), device=flat_g.device, requires_grad=True), flat_g=flat_g, grads={n: v for (n, _), v in zip(named, views)},
+                  named=named, fresh=True)
+        object.__setattr__(self, "_flat", fl)
+        return fl
+
+    def unbind_flat_grads(self, keep_grads=False):
+        """keep_grads: the gradients of the last backward stay in ``p.grad`` (still views of the old buffer) for the step that is
+        about to consume them; parameters that were frozen meanwhile lose theirs."""
+        fl = self.__dict__.get("_flat")
+        if fl is not None:
+            object.__setattr__(self, "_flat", None)
+            for _, p in fl["named"]:
+                if not (keep_grads and p.requires_grad and not fl["fresh"]):
+                    p.grad = None
 
     @property
     def _grad_names(self):
@@ -739,7 +795,13 @@ class PaSST(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # head_dist.* is not part of the graph -- as in the reference, whose forward never touches it
             # (models/passt.py:583-595; hence find_unused_parameters=True under torch DDP there and here)
-            return _PasstFunction.apply(self, x, *[p for _, p in self._graph_params()[0]])
+            named = self._graph_params()[0]
+            fl = self._flat
+            if fl is not None:
+                if fl["named"] is named:                # same validated parameter list as at bind time
+                    return _PasstFunction.apply(self, x, fl["token"])
+                self.unbind_flat_grads()                # surgery since: the optimizer re-binds at its next step
+            return _PasstFunction.apply(self, x, *[p for _, p in named])
         logits, feat, _ = passt_forward(self, x, save=False)
         return logits, feat
 

@@ -626,6 +626,101 @@ def test_train_step_fused_optimizer_staging_equals_separate(precision):
     ts_f.close()
 
 
+def test_optim_adamw_binds_one_flat_gradient():
+    """Round 6: passt_amd.optim.AdamW over ``net.parameters()`` binds the model -- one token input to the
+    autograd node instead of 159 parameters, gradients written in place into one flat buffer, ``p.grad`` standing views of it, the
+    step ONE pa_adamw_stage launch.  Checked against the unbound optimizer (PASST_AMD_NO_FLAT_GRADS=1) on the same draws:
+    parameters bit-identical after three steps; the module contract (state_dict keys, parameters() order and identity, deepcopy)
+    untouched; two backwards without zero_grad add up like autograd's AccumulateGrad; the staged weight copies are current after
+    the step; a loaded optimizer state_dict and a frozen parameter fall back to the per-parameter path and keep training."""
+    import copy
+    from passt_amd import optim as pa_optim
+    case = dict(G.CASES["model_small_train"], seed=913)
+    x, y = G.model_inputs(case)
+    xg, yg = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def run(flat, steps=3):
+        if not flat:
+            os.environ["PASST_AMD_NO_FLAT_GRADS"] = "1"
+        try:
+            net = build(case, "bf16").train()
+            keys, ids = list(net.state_dict()), [id(p) for p in net.parameters()]
+            opt = pa_optim.AdamW(net.parameters(), lr=1e-2, weight_decay=1e-2)
+            losses = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for i in range(steps):
+                    torch.manual_seed(60 + i)
+                    opt.zero_grad()
+                    loss = bce(net(xg)[0], yg, reduction="none").mean()
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss.item()))
+            assert list(net.state_dict()) == keys and [id(p) for p in net.parameters()] == ids
+            return net, opt, losses
+        finally:
+            os.environ.pop("PASST_AMD_NO_FLAT_GRADS", None)
+
+    net_u, opt_u, l_u = run(False)
+    net_b, opt_b, l_b = run(True)
+    assert net_u._flat is None and net_b._flat is not None and opt_b._bound
+    assert l_u == l_b
+    for (k, a), (_, b) in zip(net_u.state_dict().items(), net_b.state_dict().items()):
+        assert torch.equal(a, b), k
+    fl = net_b._flat
+    named = [(n, p) for n, p in net_b.named_parameters() if not n.startswith("head_dist.")]
+    off = 0
+    for n, p in named:                                     # p.grad: standing views of the one buffer, in named_parameters() order
+        assert p.grad.data_ptr() == fl["flat_g"].data_ptr() + 4 * off and p.grad.shape == p.shape, n
+        off += p.numel()
+    assert all(p.grad is None for n, p in net_b.named_parameters() if n.startswith("head_dist."))
+    st = net_b._staged
+    assert st.cache and all(ver == st._version(p) for (ver, out, p) in st.cache.values())     # the step rewrote the bf16 copies
+    sd = opt_b.state_dict()
+    assert sorted(sd["state"][0]) == ["exp_avg", "exp_avg_sq", "step"] and float(sd["state"][0]["step"]) == 3.0
+    # gradient accumulation: two backwards without zero_grad == the sum of the two gradients
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt_b.zero_grad()
+        torch.manual_seed(70)
+        bce(net_b(xg)[0], yg, reduction="none").mean().backward()
+        g1 = fl["flat_g"].clone()
+        torch.manual_seed(71)
+        bce(net_b(xg)[0], yg, reduction="none").mean().backward()
+        both = fl["flat_g"].clone()
+        opt_b.zero_grad()
+        torch.manual_seed(71)
+        bce(net_b(xg)[0], yg, reduction="none").mean().backward()
+        g2 = fl["flat_g"].clone()
+    assert rel(both.cpu(), (g1 + g2).cpu()) < 1e-6 and float(g2.abs().max()) > 0
+    # deepcopy (SWA): an unbound twin with the same values
+    twin = copy.deepcopy(net_b)
+    assert twin._flat is None and all(torch.equal(a, b) for a, b in zip(twin.state_dict().values(), net_b.state_dict().values()))
+    # a loaded optimizer state: separate step tensors again -> this step runs per parameter, the next one re-binds
+    opt_b.load_state_dict(copy.deepcopy(opt_b.state_dict()))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(2):
+            opt_b.zero_grad()
+            torch.manual_seed(80 + i)
+            bce(net_b(xg)[0], yg, reduction="none").mean().backward()
+            before = net_b.blocks[0].mlp.fc1.weight.detach().clone()
+            opt_b.step()
+            assert not torch.equal(before, net_b.blocks[0].mlp.fc1.weight.detach())
+    assert float(opt_b.state_dict()["state"][0]["step"]) == 5.0
+    # a frozen parameter: autograd decides which gradients exist -> unbound, still trains
+    net_b.cls_token.requires_grad_(False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(2):
+            opt_b.zero_grad()
+            torch.manual_seed(90 + i)
+            bce(net_b(xg)[0], yg, reduction="none").mean().backward()
+            opt_b.step()
+    assert net_b.cls_token.grad is None or net_b._flat is None
+
+
 def test_swa_matches_reference_update_rule():
     """schedule.SWA (one fused kernel on the flat buffer) == helpers/swa_callback.py:246-268 applied per tensor
     (restated here: avg = p for the first snapshot, then avg + (p - avg) / (n + 1)); copy_to() loads a deepcopy."""
