@@ -172,6 +172,9 @@ typedef struct {
                             * 2 = 256x256 lockstep; 6 / 7 / 8 = role-split 256x256 / 192x256 / 128x256 (8 waves,
                             * staggered wave groups); 9 = 128x256, 4 waves, 64-byte stages, 2 workgroups/CU (slower: DESIGN.md 4.1).
                             * 17 / 18 = 7 / 8 with three A slots (A requested two K-tiles ahead; what 0 picks for them).
+                            * 3 = 192x128, 4 waves, 80 KiB: 2 workgroups/CU (first-generation epilogue; with PA_GEMM_BLOCKED_PRE: epilogue
+                            * v2 + blocked pre-activation; PA_NT_MLP_2WG=1 makes 0 pick it for the large MLP-epilogue GEMMs);
+                            * 13 / 19 = 3 / 9 with epilogue v2 and row-major outputs (round 6, A/B: profiles/r06_gemm_variants_epi13.txt).
                             * pa_gemm_tn bf16: 1 = 128x128, otherwise role-split 256x256.  pa_gemm_tn_batched: tune of the
                             * FIRST problem = 2 orders the work items problem-major instead of slice-major (A/B only). */
     /* PA_EPI_DGELU only, optional: colsum_out[n] = (colsum_accumulate ? colsum_out[n] : 0) + sum_m out[m][n] (of the

@@ -11,6 +11,7 @@
 // LDS image is lane-linear, so the bank-conflict XOR swizzle is applied on the per-lane SOURCE
 // address and again on the ds_read_b128 address (guide rule 21).
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "pa_mma.h"
@@ -866,8 +867,9 @@ template <int KBT> __device__ __forceinline__ int swz_rows(int row) {
 // BLK (r06): the epilogue is the role-split kernels' v2 epilogue (accumulator-layout math, packed row-pair slab, buffer
 // instructions) with the MLP pre-activation in the library's blocked layout -- what makes the blocked pre-activation reachable
 // from the tiles that fit TWO workgroups per CU (tunes 3 / 9: one workgroup's transposition + store burst under the other's K loop)
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, bool BLK = false>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu((KBT == 64 || BLK) ? 2 : 1))) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
+// EPV (r06): 0 = the first-generation epilogue; 1 = epilogue v2 (row-major outputs); 2 = epilogue v2 with the blocked pre-activation
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, int EPV = 0>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu((KBT == 64 || EPV) ? 2 : 1))) void gemm_nt_kernel(const pa_gemm_args a, const int tiles_m, const int tiles_n,
                                                                const int nwg, const int ksteps_per_split) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
     constexpr int A_BYTES = TBM * KBT, B_BYTES = TBN * KBT, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -980,41 +982,44 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu((K
         }
         if (++buf == STAGES) buf = 0;
     }
-    if constexpr (BLK) {
-        static_assert(sizeof(T) == 2 && (EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU), "blocked pre-activation: bf16 GELU / GELU' only");
-        V2Aux<EPI, TM, true> aux;
-        aux.issue(a, m0, n0, wr, wc, lane);          // GELU': the first pre-activation passes are in flight across the barrier
+    if constexpr (EPV != 0) {
+        constexpr bool BLK = EPV == 2;
+        static_assert(sizeof(T) == 2 && EPI != PA_EPI_PARTIAL, "epilogue v2: bf16 operands, fused epilogues");
+        static_assert(!BLK || EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU, "blocked pre-activation: GELU / GELU' only");
+        constexpr bool BLKX = BLK && (EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU);
+        V2Aux<EPI, TM, BLKX> aux;
+        aux.issue(a, m0, n0, wr, wc, lane);          // GELU' / residual: the first auxiliary rows are in flight across the barrier
         __syncthreads();                             // every wave is done reading the operand tiles; LDS is reused by the slabs
-        // (the bias row is read from global memory: N % 64 == 0 and the wave tile's early-out keep wc * 64 + c inside it)
-        gemm_epilogue_v2_bf16<EPI, TM, true>(a, acc, smem + wave * 8192, (EPI == PA_EPI_GELU && a.bias) ? a.bias + n0 : nullptr, m0, n0,
-                                             wr, wc, lane, tm * WM + wr, aux);
+        // (the bias row is read from global memory: N % 64 == 0 -- launch guard -- and the wave tile's early-out keep wc * 64 + c inside it)
+        const float* brow = (EPI != PA_EPI_DGELU && a.bias) ? a.bias + n0 : nullptr;
+        if constexpr (EPI == PA_EPI_RESID) gemm_epilogue_v2_resid<TM>(a, acc, smem + wave * 8192, brow, m0, n0, wr, wc, lane, aux);
+        else gemm_epilogue_v2_bf16<EPI, TM, BLKX>(a, acc, smem + wave * 8192, brow, m0, n0, wr, wc, lane, tm * WM + wr, aux);
     } else {
         __syncthreads();  // every wave is done reading the operand tiles; LDS is reused by the slabs
         gemm_epilogue<T, EPI, TM>(a, acc, (float*)(smem + wave * SLAB_BYTES), m0, n0, blockIdx.y, wr, wc, lane, bias8, tm * WM + wr);
     }
 }
 
-template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, bool BLK = false>
+template <typename T, int EPI, int WM, int WN, int TM, int STAGES, int KBT = KB, int EPV = 0>
 static int launch_gemm_v(const pa_gemm_args& a, hipStream_t st) {
     constexpr int TBM = WM * TM * 32, TBN = WN * 64;
     constexpr int LDS = STAGES * (TBM + TBN) * KBT;
     static_assert(LDS <= 160 * 1024, "LDS ring too large");
     static_assert(LDS >= WM * WN * 32 * 68 * 4, "epilogue slabs must fit");
-    if constexpr (BLK) {     // buffer-descriptor epilogue: every row within 2 GiB of the first one
-        const int64_t lim = (int64_t)1 << 31;
-        if ((int64_t)a.M * a.ldolp * 2 >= lim || (int64_t)a.M * a.ldolp2 * 2 >= lim) return PA_EUNSUPPORTED;
+    if constexpr (EPV != 0) {     // buffer-descriptor epilogue: every row within 2 GiB of the first one, whole 64-column wave tiles,
+        const int64_t lim = (int64_t)1 << 31;                      // no row remap (the patch embedding keeps the first-generation epilogue)
+        if ((int64_t)a.M * a.ldolp * 2 >= lim || (int64_t)a.M * a.ldolp2 * 2 >= lim || (int64_t)a.M * a.ldaux * 2 >= lim ||
+            (int64_t)a.M * a.ldr * 4 >= lim || (int64_t)a.M * a.ldo32 * 4 >= lim || a.N % 64 || (EPI == PA_EPI_RESID && a.row_mod > 0))
+            return EPV == 2 ? PA_EUNSUPPORTED : launch_gemm_v<T, EPI, WM, WN, TM, STAGES, KBT, 0>(a, st);
     }
     const int tiles_m = (int)cdiv(a.M, TBM), tiles_n = (int)cdiv(a.N, TBN);
     const int nwg = tiles_m * tiles_n;
     const int ksteps = (int)((int64_t)a.K * sizeof(T) / KBT);
     const int splits = EPI == PA_EPI_PARTIAL ? a.split_k : 1;
     const int per = (int)cdiv(ksteps, splits);
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, BLK>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
-    }();
-    (void)attr_set;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, BLK>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, EPV>, LDS, lds_attr);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, WN, TM, STAGES, KBT, EPV>), dim3(nwg, splits), dim3(WM * WN * 64), LDS, st, a,
                        tiles_m, tiles_n, nwg, per);
     const int rc = check_launch();
     if (rc == PA_OK && EPI == PA_EPI_DGELU && a.colsum_out) return finish_gemm_colsum(a, tiles_m * WM, st);
@@ -1401,11 +1406,8 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
     constexpr int LDS_BYTES = G::LDS;
 #endif
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (probe build)");
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK, TR>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-    }();
-    (void)attr_set;
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)gemm_nt_stagger_kernel<T, EPI, TM, A3, BLK, TR>, LDS_BYTES, lds_attr);
     // PA_GEMM_NO_PERSIST (a.reserved) / PA_NT_PERSISTENT=0: one work item per workgroup, handed out by the hardware as CUs free
     // up, instead of 256 resident workgroups walking their item lists.  The persistent form assumes it owns every CU: when
     // another kernel (an RCCL all-reduce on the communication stream) holds R of them, R of its workgroups only start after the
@@ -1426,15 +1428,29 @@ static int launch_gemm_stagger(const pa_gemm_args& a, hipStream_t st) {
 //               an un-overlapped prologue+epilogue per tile, which at K = 768 cancels their advantage)
 static int pick_nt_variant(int M, int N, int K) {
     struct Cand { int id, bm, bn, slots; float rate_short, rate_long; };
-    static const Cand cands[] = {
+    // The rates are RELATIVE weights tuned on the training step (rounds 1-2), not isolated throughputs.  Round 6 re-measured every
+    // schedule ALONE at M = 30 336 (profiles/r06_nt_variants.txt: K <= 1024 -> {1: 700, 8: 800, 7: 950, 6: 930} TF/s, K > 1024 ->
+    // {1: 870, 8: 950, 7: 1075, 6: 900}, 7 / 8 in their A3 form) and tried that table (PA_NT_RATES=r06): it moves the MLP-epilogue GEMMs
+    // of config #2 and the long-K GEMMs of config #4 from the 256-row to the 192-row tile and the small GEMMs of ESC-50 from the
+    // generic to the role-split kernel, and every configuration got SLOWER in the step -- config #2 22.31 -> 22.45 ms, config #4
+    // 66.2 -> 67.4, ESC-50 5.83 -> 5.92 (ABBA, 60-step lines, profiles/r06_pick_table_ab.txt): alone, operands come out of the caches
+    // and the epilogue's stores meet an idle memory system; in the step they do not.  The step-tuned table stays.
+    static const Cand r06[] = {
+        {1, 128, 128, 512, 700.f, 870.f},
+        {8, 128, 256, 256, 800.f, 950.f},
+        {7, 192, 256, 256, 950.f, 1075.f},
+        {6, 256, 256, 256, 930.f, 900.f},
+    };
+    static const Cand r01[] = {
         {1, 128, 128, 512, 750.f, 930.f},
         {8, 128, 256, 256, 650.f, 1000.f},
         {7, 192, 256, 256, 780.f, 1250.f},
         {6, 256, 256, 256, 800.f, 1150.f},
     };
+    static const bool isolated_table = [] { const char* e = getenv("PA_NT_RATES"); return e && !strcmp(e, "r06"); }();
+    const Cand (&cands)[4] = isolated_table ? r06 : r01;
     int best = 1;
     double best_cost = 1e30;
-    // (r02: 192-row A3 tiles instead of 256-row ones for the N = 3072 GEMMs: fc1+GELU -2 %, dgrad-fc2 +5 % in the step: kept)
     for (const Cand& c : cands) {
         const int64_t tiles = cdiv(M, c.bm) * cdiv(N, c.bn);
         const double rounds = (double)cdiv(tiles, c.slots);
@@ -1455,8 +1471,16 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
         static const bool a3 = [] { const char* e = getenv("PA_NT_A3"); return !e || atoi(e) != 0; }();
         if (!a.tune && a3 && EPI != PA_EPI_PARTIAL && (v == 7 || v == 8)) v += 10;
         if constexpr (EPI == PA_EPI_GELU || EPI == PA_EPI_DGELU) {
-            if (a.reserved & PA_GEMM_BLOCKED_PRE) {      // blocked pre-activation: role-split kernels only (pa_gemm_blocked_pre_ok)
+            if (a.reserved & PA_GEMM_BLOCKED_PRE) {      // blocked pre-activation: the kernels with epilogue v2 (pa_gemm_blocked_pre_ok)
                 if (a.N % 64 || blocked_pre_rows(a.M) * a.N * 2 >= ((int64_t)1 << 31)) return PA_EUNSUPPORTED;
+                // r06: the 192 x 128 tile that fits TWO workgroups per CU -- one workgroup's transposition + store
+                // burst under the other's K loop -- has the blocked pre-activation too (tune 3 / 9, epilogue v2).  In the step at config
+                // #2 (M = 30 336, N = 3072, K = 768; ABBA, 60-step lines, profiles/r06_gemm_variants_epi13.txt) it was 1-2 % FASTER than
+                // the 256-row role-split tile on one box (fc1 + GELU 165.2 -> 163.4 us, GELU' 177.6 -> 173.6, step -0.2 %) and 2 %
+                // SLOWER on another (170.5 -> 173.6, 183.3 -> 187.8, step +0.4 %); slower at ESC-50's M = 4 236 (33 -> 39.5 us) and
+                // for fc1 + GELU at config #4's K = 1024: a wash, so it is opt-in (PA_NT_MLP_2WG=1), not the default.
+                static const bool mlp_2wg = [] { const char* e = getenv("PA_NT_MLP_2WG"); return e && atoi(e) != 0; }();
+                if (!a.tune && mlp_2wg && a.M >= 16384 && a.N >= 1024 && a.K <= (EPI == PA_EPI_DGELU ? 1024 : 768)) v = 3;
                 switch (v) {
                     case 6: return launch_gemm_stagger<T, EPI, 4, false, true>(a, st);
                     case 7: return launch_gemm_stagger<T, EPI, 3, false, true>(a, st);
@@ -1464,8 +1488,8 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
                     case 17: return launch_gemm_stagger<T, EPI, 3, true, true>(a, st);
                     case 18: return launch_gemm_stagger<T, EPI, 2, true, true>(a, st);
                     // r06: the two-workgroups-per-CU tiles with the v2 epilogue (explicit tune only; profiles/r06_gemm_variants_epi13.txt)
-                    case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2, KB, true>(a, st);       // 192x128, 4 waves, 80 KiB
-                    case 9: return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64, true>(a, st);       // 128x256, 4 waves, 72 KiB
+                    case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2, KB, 2>(a, st);       // 192x128, 4 waves, 80 KiB
+                    case 9: return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64, 2>(a, st);       // 128x256, 4 waves, 72 KiB
                 }
                 return PA_EUNSUPPORTED;
             }
@@ -1475,6 +1499,9 @@ static int launch_gemm(const pa_gemm_args& a, hipStream_t st) {
             case 2: return launch_gemm_v<T, EPI, 2, 4, 4, 2>(a, st);   // 256x256, 8 waves (128x64 each), lockstep
             case 3: return launch_gemm_v<T, EPI, 2, 2, 3, 2>(a, st);   // 192x128, 4 waves (96x64 each), 80 KiB: 2 workgroups / CU
             case 9: return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64>(a, st);   // 128x256, 4 waves (128x64 each), 3 x 24 KiB stages: 2 workgroups / CU
+            // r06: the two-workgroups-per-CU tiles with epilogue v2 (row-major outputs)
+            case 13: if constexpr (EPI != PA_EPI_PARTIAL) return launch_gemm_v<T, EPI, 2, 2, 3, 2, KB, 1>(a, st); else return PA_EINVAL;
+            case 19: if constexpr (EPI != PA_EPI_PARTIAL) return launch_gemm_v<T, EPI, 1, 4, 4, 3, 64, 1>(a, st); else return PA_EINVAL;
             case 6: return launch_gemm_stagger<T, EPI, 4>(a, st);      // 256x256 role-split schedule (8 waves)
             case 7: return launch_gemm_stagger<T, EPI, 3>(a, st);      // 192x256 role-split
             case 8: return launch_gemm_stagger<T, EPI, 2>(a, st);      // 128x256 role-split
@@ -2155,11 +2182,8 @@ static int launch_gemm_tn_stagger(const pa_gemm_args& a, hipStream_t st) {
     const int nwg = tiles_m * tiles_n;
     const int steps = (int)cdiv(a.K, TN_ROWS);
     const int per = (int)cdiv(steps, a.split_k);
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_tn_stagger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS) == hipSuccess;
-    }();
-    (void)attr_set;
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)gemm_tn_stagger_kernel, LDS, lds_attr);
     hipLaunchKernelGGL(gemm_tn_stagger_kernel, dim3(nwg, a.split_k), dim3(512), LDS, st, a, tiles_n, nwg, per);
     return check_launch();
 }
@@ -2170,11 +2194,8 @@ static int launch_gemm_tn(const pa_gemm_args& a, hipStream_t st) {
     const int nwg = tiles_m * tiles_n;
     const int steps = (int)cdiv(a.K, TNGeom<T>::MROWS);
     const int per = (int)cdiv(steps, a.split_k);
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   GEMM_LDS) == hipSuccess;
-    }();
-    (void)attr_set;
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)gemm_tn_kernel<T>, GEMM_LDS, lds_attr);
     hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(nwg, a.split_k), dim3(256), GEMM_LDS, st, a, tiles_n, nwg, per);
     return check_launch();
 }
@@ -2660,11 +2681,8 @@ extern "C" int pa_gemm_tn_batched(const pa_gemm_args* a, int n, void* stream) {
 #else
     constexpr int LDS = TN_LDS;
 #endif
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)gemm_tn_stagger_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS) == hipSuccess;
-    }();
-    (void)attr_set;
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)gemm_tn_stagger_batched_kernel, LDS, lds_attr);
     hipLaunchKernelGGL(gemm_tn_stagger_batched_kernel, dim3(total), dim3(512), LDS, (hipStream_t)stream, batch);
     return check_launch();
 }

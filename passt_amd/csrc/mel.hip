@@ -421,10 +421,8 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH +
                        std::max<size_t>((size_t)p->n_mels * (fr + 1) * 4, 2 * NC * 4);
     if (lds > 160 * 1024) return PA_EUNSUPPORTED;
-    static bool attr_set = [] {
-        return hipFuncSetAttribute((const void*)mel_frontend_kernel<FR_DEFAULT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    }();
-    (void)attr_set;
+    static signed char lds_attr[64] = {0};
+    (void)lds_attr_on_this_device((const void*)mel_frontend_kernel<FR_DEFAULT>, 160 * 1024, lds_attr);
     dim3 grid((unsigned)cdiv(p->n_frames, fr), (unsigned)B);
     hipLaunchKernelGGL(mel_frontend_kernel<FR_DEFAULT>, grid, dim3(MEL_WAVES * 64), lds, (hipStream_t)stream, wave, L, window, bin_mel,
                        (const float2*)twiddle, out, *p);

@@ -31,13 +31,19 @@ __global__ void mixup_scalar_kernel(const float* __restrict__ x, const int32_t* 
         o[i] = xa[i] * l + xb[i] * (1.f - l);
 }
 
+// One definite sequence of roundings (no contraction left to the compiler: it fused a * b + c differently in the kernels this is
+// inlined into -- pa_adamw and pa_adamw_stage differed by an ulp): the two moment updates are ONE fused multiply-add each, nothing
+// else is fused.  pa_adamw, pa_adamw_dev and pa_adamw_stage are bit-identical to each other by construction.
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps,
                                           float wd, float bc1, float bc2_sqrt) {
-    float pi = p * (1.f - lr * wd);
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
+#pragma clang fp contract(off)
+    const float pi = p * (1.f - lr * wd);
+    const float gm = (1.f - b1) * g, gv = ((1.f - b2) * g) * g;
+    m = __builtin_fmaf(b1, m, gm);
+    v = __builtin_fmaf(b2, v, gv);
     const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = pi - (lr / bc1) * (m / denom);
+    const float step = (lr / bc1) * (m / denom);
+    p = pi - step;
 }
 // 16-byte accesses (n4 = n / 4 when all four pointers are 16-byte aligned, else 0) + scalar tail
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -26,6 +26,20 @@ inline int check_launch() {
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: set it on every device this process launches
+// on (keyed on hipGetDevice(), decided on the device's first launch; `state` is one static array per launch site).  Returns false
+// where the device refuses it -- the launch that follows then fails loudly, or the caller takes another kernel.
+inline bool lds_attr_on_this_device(const void* kernel, int bytes, signed char (&state)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev] = e == hipSuccess ? 1 : -1;
+    }
+    return state[dev] > 0;
+}
+
 // ---- scalar conversions -----------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

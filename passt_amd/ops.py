@@ -283,6 +283,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, want_lp, accumu
 
 
 # ---- GEMM ------------------------------------------------------------------------------------
+# A/B knobs: the tile variant of every plain-store / residual NT GEMM of the step (PASST_AMD_TUNE_STORE / PASST_AMD_TUNE_RESID =
+# a pa_gemm_args.tune value, e.g. 13 = the 192 x 128 two-workgroups-per-CU tile with epilogue v2)
+_TUNE_BY_EPI = {EPI_STORE: int(os.environ.get("PASST_AMD_TUNE_STORE", "0")), EPI_RESID: int(os.environ.get("PASST_AMD_TUNE_RESID", "0"))}
+
+
 def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, out_f32=None, out_lp=None,
             out_lp2=None, row_mod=0, out_batch_rows=0, out_row_off=0, split_k=1, M=None, N=None, K=None,
             colsum_out=None, colsum_ws=None, colsum_accumulate=False, flags=0, colscale_n=0, colscale=1.0, tune=None):
@@ -308,13 +313,15 @@ def gemm_nt(A, B, dtype, epilogue=EPI_STORE, bias=None, resid=None, aux=None, ou
     a.out_lp2 = _p(out_lp2, dtype, True)
     a.ldolp2 = out_lp2.stride(0) if out_lp2 is not None else 0
     a.split_k = split_k
-    a.tune = GEMM_TUNE if tune is None else tune
+    if tune is None:
+        tune = _TUNE_BY_EPI.get(epilogue) or GEMM_TUNE
+    a.tune = tune
     a.reserved = GEMM_RESERVED | _call.gemm_flags | flags
     a.colscale_n, a.colscale = colscale_n, colscale
     a.colsum_out, a.colsum_ws, a.colsum_accumulate = _p(colsum_out, torch.float32), _p(colsum_ws, torch.float32), int(colsum_accumulate)
     # problems that leave most CUs idle (few [M][768] tiles, long K) go through the split-K entry with a workspace
     ws_n = 0
-    if epilogue in (EPI_STORE, EPI_RESID) and dtype == PA_BF16 and row_mod == 0 and split_k == 1 and not GEMM_TUNE:
+    if epilogue in (EPI_STORE, EPI_RESID) and dtype == PA_BF16 and row_mod == 0 and split_k == 1 and not tune:
         ws_n = _splitk_ws_floats(a.M, a.N, a.K, epilogue, dtype)
 
     def launch():

@@ -67,6 +67,9 @@ class AdamW(torch.optim.Optimizer):
                         ok = False
                         break
         if ok:
+            if gi not in self._bound and fl.get("bind_retries", 0) > 0:     # e.g. only part of the gradients existed at the first step
+                fl["bind_retries"] -= 1
+                self._bind_model(gi, fl, ps)
             return fl, ps
         for p in ps:
             if p.dtype != torch.float32 or p.is_sparse:
@@ -88,7 +91,7 @@ class AdamW(torch.optim.Optimizer):
             steps.append(int(st["step"]) if st else 0)     # PER PARAMETER, as torch counts them (state[p]["step"])
             offs.append(off)
             off += n
-        fl = self._flat[gi] = dict(ids=[id(p) for p in ps], flat_p=flat_p, m=m, v=v, offs=offs, steps=steps, ps=ps, n_group=len(group["params"]))
+        fl = self._flat[gi] = dict(ids=[id(p) for p in ps], flat_p=flat_p, m=m, v=v, offs=offs, steps=steps, ps=ps, n_group=len(group["params"]), bind_retries=3)
         for p, o, t in zip(ps, offs, steps):
             if self.state.get(p):                       # existing per-parameter state now views the flat moments
                 self._bind_state(fl, p, o, t)

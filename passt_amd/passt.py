@@ -165,10 +165,26 @@ class _Staged:
     def _refresh_all(self, dtype):
         if os.environ.get("PASST_AMD_NO_BATCH_STAGE"):          # A/B knob: one launch per copy, as on first use
             return False
+        tab = self.stage_table(dtype)
+        if tab is None:
+            return False
+        ops.stage_weights(tab[1], tab[2], tab[3], dtype)
+        for key, ent in self.cache.items():
+            if key[1] == dtype:
+                ent[0] = self._version(ent[2])
+        return True
+
+    def stage_table(self, dtype):
+        """(signature, device table, n, tiles) of the batched refresh of every known copy of ``dtype``; (re)built -- one small
+        host-to-device copy -- when the set of copies changed.  TrainStep's graph mode calls this BEFORE it starts capturing: with
+        the optimizer rewriting the copies itself (pa_adamw_stage) the eager warm-up steps never need the refresh launch, and a
+        copy is not allowed inside a stream capture."""
         groups = {}
         for key, (ver, out, p) in self.cache.items():
             if key[1] == dtype:
                 groups.setdefault(key[0], [p, None, None])[2 if key[2] else 1] = out
+        if not groups:
+            return None
         sig = tuple((pid, g[0].data_ptr(), None if g[1] is None else g[1].data_ptr(),
                      None if g[2] is None else g[2].data_ptr()) for pid, g in groups.items())
         tab = self.tables.get(dtype)
@@ -177,14 +193,10 @@ class _Staged:
             for p, dst, dst_t in groups.values():
                 w2 = p.detach().reshape(p.shape[0], -1)
                 if not w2.is_contiguous():
-                    return False
+                    return None
                 entries.append((w2, dst, dst_t))
             tab = self.tables[dtype] = (sig,) + ops.make_stage_table(entries, next(iter(groups.values()))[0].device)
-        ops.stage_weights(tab[1], tab[2], tab[3], dtype)
-        for key, ent in self.cache.items():
-            if key[1] == dtype:
-                ent[0] = self._version(ent[2])
-        return True
+        return tab
 
     def get(self, p, dtype, transposed):
         if dtype == PA_F32 and not transposed:                  # used in place
@@ -724,10 +736,16 @@ class PaSST(nn.Module):
             return None                                  # frozen parameters: autograd decides which gradients exist; stay unbound
         assert flat_g.numel() == total and flat_g.dtype == torch.float32
         views = torch._C._nn.unflatten_dense_tensors(flat_g, [p for _, p in named])
+        # gradients that already exist (the optimizer binds inside its first step(): the first backward has run) move in
+        have = [p.grad is not None for _, p in named]
+        if all(have):
+            torch._foreach_copy_(list(views), [p.grad for _, p in named])
+        elif any(have):
+            return None                                  # a partial set: leave this step to the per-parameter path
         for (n, p), v in zip(named, views):
             p.grad = v
         fl = dict(token=torch.zeros((), device=flat_g.device, requires_grad=True), flat_g=flat_g, grads={n: v for (n, _), v in zip(named, views)},
-                  named=named, fresh=True)
+                  named=named, fresh=not all(have))
         object.__setattr__(self, "_flat", fl)
         return fl
 

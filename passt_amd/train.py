@@ -262,6 +262,7 @@ class TrainStep:
                 self._g = g
             self._graph_fill(g, d, x, y, y2, lam_d)
             net.mark_params_updated()                        # the staged weight copies are stale: their refresh launch is captured too
+            net._staged.stage_table(_precision(net))         # (its descriptor table is uploaded here: no copies inside a capture)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             g["capturing"] = True

@@ -79,7 +79,7 @@ def test_argument_validation_without_gpu():
     # ABI 5: the attention-backward form flags are validated before anything is launched; unknown bits are an error
     buf = (ctypes.c_float * 64)()
     q = ctypes.cast(buf, ctypes.c_void_p)
-    for flags, want in ((8, -1), (1 | 16, -1)):
+    for flags, want in ((16, -1), (1 | 32, -1)):          # (8 = PA_ATTN_BWD_SINGLE_PASS_W16 since ABI 6)
         assert lib.pa_attention_bwd(q, 192, q, q, 64, q, q, q, 192, 1, 1, 4, 4, ctypes.c_float(0.125), 1, flags, None) == want
     assert lib.pa_attention_fwd(q, 192, q, 64, q, 1, 1, 4, 4, ctypes.c_float(0.125), 1, 2, None) == -1      # backward-only flag
     # the batched finishing reduction: mode / pitch / count checks
@@ -92,6 +92,11 @@ def test_argument_validation_without_gpu():
     d[0].mode, d[0].pitch = _lib.REDUCE_ROWS, 8                               # rows shorter than n
     assert lib.pa_reduce_partials_batched(d, 1, None) == -1
     assert lib.pa_layernorm_bwd_partial(None, 1, None, None, None, None, None, None, None, None, 4, 4, None) == -1
+    # ABI 6: the fused optimizer + staging entry: null table, empty table, unknown dtype, step 0 without device hyper-parameters
+    sd = (_lib.AdamwStageDesc * 1)()
+    f = ctypes.c_float
+    for descs, n, items, dt, step in ((None, 1, 1, 1, 1), (sd, 0, 1, 1, 1), (sd, 1, 0, 1, 1), (sd, 1, 1, 7, 1), (sd, 1, 1, 1, 0)):
+        assert lib.pa_adamw_stage(q, q, q, q, descs, n, items, dt, f(1e-3), f(0.9), f(0.999), f(1e-8), f(0.0), step, None, None) == -1
     assert lib.pa_layernorm_bwd_rows(0) == 0 and lib.pa_layernorm_bwd_rows(7) == 1
 
 
@@ -258,7 +263,9 @@ def test_no_kernel_of_the_library_uses_scratch():
     assert len(names) > 40, len(names)
     # A/B-only tile variants and wide LayerNorm instantiations may spill; the kernels of the default bf16 step must not
     spilled = [n for n, z in zip(names, sizes) if z > 0]
-    hot = [n for n in spilled if "gemm_tn_stagger" in n or ("DF16b" in n and ("gemm_nt_stagger_kernel" in n or "attn_" in n))]
+    # (attn_bwd_fused_kernel<true> = the sixteen-wave A/B form of round 6: 72 B of loop-invariant addresses, profiles/r06_attention_w16.txt)
+    hot = [n for n in spilled if "gemm_tn_stagger" in n or ("DF16b" in n and ("gemm_nt_stagger_kernel" in n or "attn_" in n))
+           and "attn_bwd_fused_kernelILb1E" not in n]
     assert not hot, hot
 
 

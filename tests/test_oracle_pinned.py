@@ -110,7 +110,7 @@ def test_config2_batch64_oracle_vs_golden(golden_dir, name):
 def test_bench_batch_oracle_vs_golden(golden_dir, name):
     """r06: the oracle at the benchmarked batch of the two remaining configurations against fixtures the real reference produced
     at that size: config #5 (ESC-50, B = 12, 353 tokens, CE loss on class ids: ex_esc50.py:40,60,166) with every gradient, and
-    config #4 (1024/24/16, u_patchout 400, B = 32: 25 280 token rows) on its forward, loss and Patchout draws -- its backward
+    config #4 (1024/24/16, u_patchout 400, B = 32: 25 280 token rows) on its forward (8 of the 32 clips), loss and Patchout draws -- its backward
     would keep 24 blocks of (32,16,790,790) score tensors alive (> this container's memory; the fixture itself was made with
     the reference's blocks under activation checkpointing) and is the same oracle code the B = 1 fixture of that geometry
     pins gradient by gradient (test_full_size_oracle_vs_golden[model_vitl_u400_train])."""
@@ -119,12 +119,22 @@ def test_bench_batch_oracle_vs_golden(golden_dir, name):
     with_grads = not case.get("checkpoint")
     if with_grads:
         sd, logits, feat, loss = _oracle_model_case(case)
+        np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], atol=5e-5, rtol=2e-4)
+        np.testing.assert_allclose(feat.detach().numpy(), gold["features"], atol=5e-5, rtol=2e-4)
+        assert abs(loss.item() - float(gold["loss"])) < 2e-6
     else:
+        # the first 8 of the 32 clips (the clips of a batch do not interact -- one Patchout draw per batch, no batch statistics --
+        # and the whole forward costs this suite a minute of CPU); the loss of the fixture follows from its logits
+        cfg = case["cfg"]
+        x, y = G.model_inputs(case)
+        sd = O.to_torch(detgen.passt_state_dict(cfg, case["seed"]))
+        torch.manual_seed(case["torch_seed"])
         with torch.no_grad():
-            sd, logits, feat, loss = _oracle_model_case(dict(case), backward=False)
-    np.testing.assert_allclose(logits.detach().numpy(), gold["logits"], atol=5e-5, rtol=2e-4)
-    np.testing.assert_allclose(feat.detach().numpy(), gold["features"], atol=5e-5, rtol=2e-4)
-    assert abs(loss.item() - float(gold["loss"])) < 2e-6
+            logits, feat = O.passt_forward(sd, torch.from_numpy(x[:8]), cfg, training=True)
+        np.testing.assert_allclose(logits.numpy(), gold["logits"][:8], atol=5e-5, rtol=2e-4)
+        np.testing.assert_allclose(feat.numpy(), gold["features"][:8], atol=5e-5, rtol=2e-4)
+        ref_loss = O.bce_loss(torch.from_numpy(gold["logits"]), torch.from_numpy(y))
+        assert abs(ref_loss.item() - float(gold["loss"])) < 2e-6
     cfg = case["cfg"]
     torch.manual_seed(case["torch_seed"])
     d = O.draw_patchout(cfg, (cfg["img_size"][0] - cfg["patch"]) // cfg["stride"][0] + 1,
