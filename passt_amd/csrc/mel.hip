@@ -31,6 +31,7 @@
 // stored instead of P) in loops unrolled four-fold with independent accumulators.  (Rejected: LDS float atomics for a
 // bin-parallel mel product -- 2.4x slower than the band loops, 402 vs 164 us: same-address ds_add_f32 serialise.)
 #include <algorithm>
+#include <cstdlib>
 
 #include "pa_common.h"
 
@@ -45,6 +46,12 @@ static constexpr int FR_DEFAULT = PA_MEL_FRAMES;  // frames per workgroup (templ
 static constexpr int MEL_WAVES = 4;
 #ifndef PA_MEL_ABL
 #define PA_MEL_ABL 0
+#endif
+#ifndef PA_MEL_LEAN_PERSIST
+#define PA_MEL_LEAN_PERSIST 8             // the persistent form carries the tile bookkeeping too: every untangle twiddle from one copy (no scratch:
+#endif                                    // a scratch reload in the frame loop would wait for the span DMA in flight -- vmcnt retires in order)
+#ifndef PA_MEL_PERSIST_FRAMES
+#define PA_MEL_PERSIST_FRAMES 8           // frames per tile of the persistent form (two per wave; 32-byte output rows; 49 KiB: three workgroups per CU)
 #endif
 #ifndef PA_MEL_LEAN
 #define PA_MEL_LEAN 3                     // how many of the untangle twiddles use the one-copy product (register budget: 168)
@@ -121,16 +128,25 @@ __device__ __forceinline__ cf tw1024(const float2* __restrict__ tw, int j) {
     return (j & 512) ? cf{-t.x, -t.y} : cf{t.x, t.y};
 }
 
-template <int FR_PER_WG>
-__global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const float* __restrict__ wave, int L,
+// PERSIST (round 6): the workgroup walks tiles of FR_PER_WG frames (tile = blockIdx.x, + gridDim.x, ...).  The per-lane constants and
+// the filterbank geometry are worked out ONCE per workgroup; the signal span of tile k + 1 is requested by LDS-DMA (global_load_lds: no
+// registers, raw samples) into the second span buffer while tile k is transformed, so neither the HBM latency of the span nor the ~40
+// table loads per lane sit in front of every 16 frames any more (they were 4.2 us of a 14 us workgroup life, profiles/r05_mel_probe.txt).
+// The pre-emphasis then happens where stage 1 reads the samples (the DMA cannot apply it); tiles that touch the reflect padding at the
+// clip edges are staged by the lanes themselves, pre-emphasised, as before (`raw` tells stage 1 which form the buffer holds).
+template <int FR_PER_WG, bool PERSIST>
+__global__ __launch_bounds__(MEL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mel_frontend_kernel(const float* __restrict__ wave, int L,
                                                             const float* __restrict__ window,
                                                             const float* __restrict__ bin_mel,
                                                             const float2* __restrict__ twiddle,
-                                                            float* __restrict__ out, const pa_mel_params p) {
+                                                            float* __restrict__ out, const pa_mel_params p,
+                                                            const int tiles_per_clip, const int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int span = (FR_PER_WG - 1) * p.hop + NFFT;
-    float* sSig = (float*)smem;                                        // [span] pre-emphasised, reflect-padded
-    char* sScr = smem + ((span * 4 + 15) & ~15);                       // [MEL_WAVES][WAVE_SCRATCH]
+    // one span buffer holds span (+ 4: the sample behind the last one, for the pre-emphasis) floats, rounded up to whole 1 KiB DMA pieces
+    const int span_bytes = PERSIST ? ((span + 4) * 4 + 1023) & ~1023 : ((span * 4 + 15) & ~15);
+    float* sSig0 = (float*)smem;                                       // [span] pre-emphasised + reflect-padded, or (PERSIST, interior) raw
+    char* sScr = smem + (PERSIST ? 2 : 1) * span_bytes;                // [MEL_WAVES][WAVE_SCRATCH]
     float* sOut = (float*)(sScr + MEL_WAVES * WAVE_SCRATCH);           // [n_mels][FR_PER_WG + 1]
     // the two per-bin tables are only needed until every lane holds its band-stage constants: they live in the
     // (not yet written) output tile; 50 KiB per workgroup at 16 frames and hop 320 = three workgroups per CU
@@ -139,7 +155,6 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
 #ifdef PA_MEL_PROBE      // probe build (tools/probe_mel.py): s_memrealtime stamps (100 MHz) of the phases of every wave, left in the output tile
     uint32_t stamp[6];       // few and 32-bit: the kernel is at its SGPR / VGPR budget, a bigger probe would change its occupancy
 #define MEL_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -147,10 +162,49 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
 #define MEL_STAMP(i) do {} while (0)
 #endif
     MEL_STAMP(0);
-    const int f0 = blockIdx.x * FR_PER_WG;
     const int T = p.n_frames;
     const int Ly = L - 1;
-    const float* x = wave + (int64_t)b * L;
+    constexpr int NT = MEL_WAVES * 64;
+    static_assert(NC == 2 * NT, "two bins per thread");
+    // tile -> (clip, first frame); non-persistent: the grid is (tiles per clip, clips)
+    int tile = PERSIST ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    int b = PERSIST ? tile / tiles_per_clip : (int)blockIdx.y;
+    int f0 = (PERSIST ? tile - b * tiles_per_clip : (int)blockIdx.x) * FR_PER_WG;
+    // a tile whose span needs no reflection and can move as 16-byte pieces (i0: sample index of sSig[0])
+    auto interior = [&](int f0_) {
+        const int i0 = f0_ * p.hop - NFFT / 2;
+        return i0 >= 0 && i0 + span + 4 <= Ly && ((i0 | L) & 3) == 0;
+    };
+    // PERSIST: request the raw span of tile (b_, f0_) into buffer `buf` by LDS-DMA: 1 KiB pieces dealt round-robin to the waves
+    auto stage_dma = [&](int buf, int b_, int f0_) {
+        const float* xs = wave + (int64_t)b_ * L + (f0_ * p.hop - NFFT / 2);
+        const int nchunk = (span + 4) >> 2;                           // 16-byte chunks covering x[0 .. span] (x[span] feeds y[span - 1])
+        // Issued by INLINE ASM, not by __builtin_amdgcn_global_load_lds: with the builtin the compiler, which cannot tell the DMA's LDS
+        // destination from the other span buffer, puts s_waitcnt vmcnt(0) in front of the next LDS read -- the first sample read of
+        // the frames -- and the prefetch overlaps nothing (measured: 101-105 us against 90-93 for the one-tile form).  The asm form is
+        // invisible to that analysis; the landing is ordered by the explicit vmcnt(0) + barrier that closes the tile's frames.  (M0 =
+        // LDS base of the piece, saved and restored around the instruction: nothing else in this kernel uses it.)
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(buf * span_bytes);
+        for (int k = wv; k * 64 < nchunk; k += MEL_WAVES) {
+            const int c = min(k * 64 + lane, nchunk - 1);
+            const float* src = xs + 4 * c;
+            uint32_t m0_keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_keep) : "s"(__builtin_amdgcn_readfirstlane(dst + (uint32_t)k * 1024u)), "v"(src) : "memory");
+        }
+    };
+    // the lanes stage the span themselves: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2 (clip edges, odd geometries)
+    auto stage_slow = [&](float* sSig, int b_, int f0_) {
+        const float* x = wave + (int64_t)b_ * L;
+        const int i0 = f0_ * p.hop - NFFT / 2;
+        for (int j = tid; j < span; j += NT) {
+            int i = i0 + j;
+            if (i < 0) i = -i;
+            if (i >= Ly) i = 2 * (Ly - 1) - i;
+            i = max(0, min(i, Ly - 1));
+            sSig[j] = x[i + 1] - p.preemph * x[i];
+        }
+    };
 
     // ---- per-lane constants: requested first, so that the (L2-resident) tables arrive while the span is staged ----
     cf tw1[8], tw2[8], tw3[8];
@@ -171,41 +225,39 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
     // ---- stage the signal span: y[i] = x[i+1] - preemph * x[i], reflect-padded by n_fft/2.  (Measured and not kept, round 5:
     // geometry + band-stage constants worked out while the span loads are in flight, the span stored last -- the prologue
     // shrinks by 0.8 us, the frames of the co-resident workgroups slow down by 0.4, the launch stays at 92 us.) ----
-    constexpr int NT = MEL_WAVES * 64;
-    static_assert(NC == 2 * NT, "two bins per thread");
     const float bm0 = bin_mel[tid], bm1 = bin_mel[tid + NT];   // requested here, used behind the span
-    const int i0 = f0 * p.hop - NFFT / 2;                    // sample index of sSig[0]
-    if (i0 >= 0 && i0 + span + 4 <= Ly && ((i0 | L) & 3) == 0 && (span & 3) == 0 && span <= 12 * 4 * NT) {
-        // interior tile (no reflection, 16-byte aligned): one 16-byte load + the next sample per 4 outputs, every
-        // load of the tile issued before the first use (the loop has a compile-time trip count)
-        const float* xs = x + i0;
-        const int nv = span >> 2;
-        constexpr int MAXIT = 12;                             // 12 x 256 x 4 samples >= span for hop <= 362
-        f32x4 a[MAXIT];
-        float nx[MAXIT];
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const int t = tid + it * NT;
-            if (it * NT < nv) {                               // uniform; the lane predicate is folded into the address
-                const int tc = min(t, nv - 1);
-                a[it] = *(const f32x4*)(xs + 4 * tc);
-                nx[it] = xs[4 * tc + 4];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const int t = tid + it * NT;
-            if (it * NT < nv && t < nv)
-                *(f32x4*)(sSig + 4 * t) = f32x4{a[it][1] - p.preemph * a[it][0], a[it][2] - p.preemph * a[it][1],
-                                                a[it][3] - p.preemph * a[it][2], nx[it] - p.preemph * a[it][3]};
-        }
+    if constexpr (PERSIST) {
+        if (interior(f0)) stage_dma(0, b, f0);
+        else stage_slow(sSig0, b, f0);
     } else {
-        for (int j = tid; j < span; j += NT) {
-            int i = i0 + j;
-            if (i < 0) i = -i;
-            if (i >= Ly) i = 2 * (Ly - 1) - i;
-            i = max(0, min(i, Ly - 1));
-            sSig[j] = x[i + 1] - p.preemph * x[i];
+        const float* x = wave + (int64_t)b * L;
+        const int i0 = f0 * p.hop - NFFT / 2;                    // sample index of sSig[0]
+        if (interior(f0) && (span & 3) == 0 && span <= 12 * 4 * NT) {
+            // interior tile (no reflection, 16-byte aligned): one 16-byte load + the next sample per 4 outputs, every
+            // load of the tile issued before the first use (the loop has a compile-time trip count)
+            const float* xs = x + i0;
+            const int nv = span >> 2;
+            constexpr int MAXIT = 12;                             // 12 x 256 x 4 samples >= span for hop <= 362
+            f32x4 a[MAXIT];
+            float nx[MAXIT];
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int t = tid + it * NT;
+                if (it * NT < nv) {                               // uniform; the lane predicate is folded into the address
+                    const int tc = min(t, nv - 1);
+                    a[it] = *(const f32x4*)(xs + 4 * tc);
+                    nx[it] = xs[4 * tc + 4];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int t = tid + it * NT;
+                if (it * NT < nv && t < nv)
+                    *(f32x4*)(sSig0 + 4 * t) = f32x4{a[it][1] - p.preemph * a[it][0], a[it][2] - p.preemph * a[it][1],
+                                                     a[it][3] - p.preemph * a[it][2], nx[it] - p.preemph * a[it][3]};
+            }
+        } else {
+            stage_slow(sSig0, b, f0);
         }
     }
     MEL_STAMP(1);
@@ -256,9 +308,28 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         sw[4] = f == 0; f |= dpp_i<0x142, 0xA>(f);           // row_bcast15 into rows 1, 3
         sw[5] = f == 0;                                      // row_bcast31 into rows 2, 3
     }
+    if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the first tile's span pieces of this wave have landed
     __syncthreads();                         // sU / sJ are dead from here on: their LDS is the output tile
     MEL_STAMP(2);
 
+    for (int it = 0;; ++it) {                 // PERSIST: the tiles of this workgroup; else one pass
+    const float* sSig = (const float*)(smem + (PERSIST ? (it & 1) * span_bytes : 0));
+    bool raw = false;
+    if constexpr (PERSIST) {
+        raw = interior(f0);
+        // this tile's span has landed (the DMA was waited for -- vmcnt(0) -- in front of the barrier that closed the previous tile's
+        // frames, or in the prologue); every wave is through the previous tile's epilogue: its output tile and the other span
+        // buffer (read by the tile before) are free
+        if (it > 0) __syncthreads();
+        const int nt_ = tile + (int)gridDim.x;
+        if (nt_ < n_tiles) {
+            const int nb = nt_ / tiles_per_clip, nf0 = (nt_ - nb * tiles_per_clip) * FR_PER_WG;
+#ifndef PA_MEL_NODMA         // timing ablation: the next tile's span is not requested (stale samples)
+            if (interior(nf0)) stage_dma((it + 1) & 1, nb, nf0);
+            else stage_slow((float*)(smem + ((it + 1) & 1) * span_bytes), nb, nf0);
+#endif
+        }
+    }
     for (int fi = 0; fi < FR_PER_WG / MEL_WAVES; ++fi) {
         const int fl = wv * (FR_PER_WG / MEL_WAVES) + fi;
         const int frame = f0 + fl;
@@ -266,10 +337,21 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         const float* sig = sSig + fl * p.hop;
         cf v[8];
         // stage 1: lane m holds z[64a + m], a = 0..7  (z[n] = y[2n] + i y[2n+1], windowed)
+        if (PERSIST && raw) {                // uniform: the buffer holds raw samples, y[j] = x[j+1] - preemph x[j] is formed here
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int n = 64 * a + lane;
-            v[a] = cf{sig[2 * n], sig[2 * n + 1]} * cf{win[2 * a], win[2 * a + 1]};
+            for (int a = 0; a < 8; ++a) {
+                const float* s2 = sig + 2 * (64 * a + lane);
+                const cf x01 = *(const cf*)s2;
+                const float x2 = s2[2];
+                const cf y = __builtin_elementwise_fma(x01, cf{-p.preemph, -p.preemph}, cf{x01.y, x2});
+                v[a] = y * cf{win[2 * a], win[2 * a + 1]};
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const int n = 64 * a + lane;
+                v[a] = cf{sig[2 * n], sig[2 * n + 1]} * cf{win[2 * a], win[2 * a + 1]};
+            }
         }
         dft8(v);
 #pragma unroll
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
             // and that factor lives in the band weights (un = u / 4: exact)
             const cf e2 = addcj(zk, zc);                       // 2 e
             const cf o2 = cmul_negi(subcj(zk, zc));            // 2 o = (Z[k] - conj Z[N-k]) / i
-            const cf X2 = e2 + (s < PA_MEL_LEAN ? cmul_lean(o2, tw3[s]) : cmul(o2, tw3[s]));               // 2 X
+            const cf X2 = e2 + (s < (PERSIST ? PA_MEL_LEAN_PERSIST : PA_MEL_LEAN) ? cmul_lean(o2, tw3[s]) : cmul(o2, tw3[s]));               // 2 X
             const cf sq = X2 * X2;
             pk[s] = sq.x + sq.y;                               // 4 |X|^2
         }
@@ -377,6 +459,7 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         if (fi == 3) MEL_STAMP(3);
 #endif
     }
+    if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA (requested a tile ago) and older stores
     __syncthreads();
     MEL_STAMP(4);
     // ---- epilogue: log, SpecAugment masks, affine; rows of FR_PER_WG frames = 64 contiguous bytes ----
@@ -387,6 +470,9 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         float v = __logf(sOut[mel * (FR_PER_WG + 1) + fl] + p.log_eps);
         const bool masked = (mel >= p.fmask_start && mel < p.fmask_end) || (t >= p.tmask_start && t < p.tmask_end);
         if (masked) v = 0.f;
+#ifdef PA_MEL_NOSTORE        // timing ablation (A/B builds only): no output stores
+        if (v != 12345.678f) continue;
+#endif
         out[((int64_t)b * p.n_mels + mel) * T + t] = (v + p.out_add) * p.out_scale;
     }
 #ifdef PA_MEL_PROBE
@@ -398,6 +484,12 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frontend_kernel(const floa
         for (int i = 1; i < 6; ++i) o[(int64_t)i * T] = (float)(stamp[i] - stamp[0]);
     }
 #endif
+    if constexpr (!PERSIST) break;
+    tile += (int)gridDim.x;
+    if (tile >= n_tiles) break;
+    b = tile / tiles_per_clip;
+    f0 = (tile - b * tiles_per_clip) * FR_PER_WG;
+    }
 }
 
 }  // namespace pa
@@ -416,15 +508,51 @@ extern "C" int pa_mel_frontend_fwd(const float* wave, int B, int L, const float*
     // profiles/r05_mel_probe.txt): 8 frames per workgroup -- 125 us against 90 at B = 64, and for grids that leave CUs without
     // their three workgroups (ESC-50 at batch 12: 384 workgroups) 23-29 us against 19: the per-workgroup set-up (4 us of a 14 us
     // life) is amortised over half the frames
+    hipStream_t st = (hipStream_t)stream;
+    // Round 6, measured and NOT adopted (profiles/r06_mel_persistent.txt): the PERSISTENT form -- resident workgroups walk tiles of 8
+    // frames, set-up once per workgroup, the next tile's span requested by LDS-DMA into a second buffer while this one is transformed
+    // (mel_frontend_kernel<., true>; needs an even hop and room for two span buffers).  97-104 us against 89-92: and with NEITHER the
+    // span requests NOR the output stores it still takes 87 us, as does the one-tile form without its stores -- the launch is bound by
+    // the frames themselves at three waves per SIMD (~3 400 cycles per frame and SIMD for ~260 VALU + ~75 LDS instructions: dependent
+    // butterfly chains and four LDS round trips per frame), not by the per-workgroup set-up the round-5 model blamed.  PA_MEL_PERSIST=1
+    // selects it (A/B, parity-tested).
+    static const int persist_env = [] { const char* e = getenv("PA_MEL_PERSIST"); return e ? atoi(e) : 0; }();
+    if (persist_env && p->hop % 2 == 0) {
+        constexpr int FRP = PA_MEL_PERSIST_FRAMES;
+        const int spanp = (FRP - 1) * p->hop + NFFT;
+        const size_t span_bytes = ((size_t)(spanp + 4) * 4 + 1023) & ~(size_t)1023;
+        const size_t ldsp = 2 * span_bytes + MEL_WAVES * WAVE_SCRATCH + std::max<size_t>((size_t)p->n_mels * (FRP + 1) * 4, 2 * NC * 4);
+        if (ldsp <= 160 * 1024) {
+            static signed char lds_attr_p[64] = {0};
+            static int cus[64] = {0};
+            int dev = 0;
+            if (lds_attr_on_this_device((const void*)mel_frontend_kernel<FRP, true>, 160 * 1024, lds_attr_p) && hipGetDevice(&dev) == hipSuccess &&
+                dev >= 0 && dev < 64) {
+                if (cus[dev] == 0) {
+                    int n = 0;
+                    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+                }
+                const int tiles_per_clip = (int)cdiv(p->n_frames, FRP);
+                const int64_t n_tiles = (int64_t)tiles_per_clip * B;
+                const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / ldsp);
+                if (n_tiles < ((int64_t)1 << 31)) {
+                    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cus[dev] * per_cu);
+                    hipLaunchKernelGGL((mel_frontend_kernel<FRP, true>), dim3((unsigned)grid), dim3(MEL_WAVES * 64), ldsp, st, wave, L, window, bin_mel,
+                                       (const float2*)twiddle, out, *p, tiles_per_clip, (int)n_tiles);
+                    return check_launch();
+                }
+            }
+        }
+    }
     const int fr = FR_DEFAULT;
     const int span = (fr - 1) * p->hop + NFFT;
     const size_t lds = ((span * 4 + 15) & ~15) + MEL_WAVES * WAVE_SCRATCH +
                        std::max<size_t>((size_t)p->n_mels * (fr + 1) * 4, 2 * NC * 4);
     if (lds > 160 * 1024) return PA_EUNSUPPORTED;
     static signed char lds_attr[64] = {0};
-    (void)lds_attr_on_this_device((const void*)mel_frontend_kernel<FR_DEFAULT>, 160 * 1024, lds_attr);
+    (void)lds_attr_on_this_device((const void*)mel_frontend_kernel<FR_DEFAULT, false>, 160 * 1024, lds_attr);
     dim3 grid((unsigned)cdiv(p->n_frames, fr), (unsigned)B);
-    hipLaunchKernelGGL(mel_frontend_kernel<FR_DEFAULT>, grid, dim3(MEL_WAVES * 64), lds, (hipStream_t)stream, wave, L, window, bin_mel,
-                       (const float2*)twiddle, out, *p);
+    hipLaunchKernelGGL((mel_frontend_kernel<FR_DEFAULT, false>), grid, dim3(MEL_WAVES * 64), lds, st, wave, L, window, bin_mel,
+                       (const float2*)twiddle, out, *p, (int)cdiv(p->n_frames, fr), (int)(cdiv(p->n_frames, fr) * B));
     return check_launch();
 }

@@ -163,6 +163,30 @@ def test_frontend_vs_golden(golden_dir, name):
     assert len(mel.state_dict()) == 0
 
 
+def test_frontend_persistent_form_equals_default(tmp_path):
+    """Round 6: the persistent, LDS-DMA-prefetching form of the front end (PA_MEL_PERSIST=1, read once per process: subprocesses)
+    against the shipped one-tile-per-workgroup form on the same waveforms -- 10 s and 5 s clips (interior tiles by DMA, clip-edge
+    tiles staged by the lanes), train-mode masks, and a length that is not a multiple of four (falls back to lane staging)."""
+    import subprocess
+    import sys
+    code = ("import sys, warnings, numpy as np, torch; warnings.simplefilter('ignore'); import passt_amd; "
+            "from tests.golden import make_golden as G; out = {}; "
+            "mel = passt_amd.AugmentMelSTFT(fmin_aug_range=10, fmax_aug_range=2000, freqm=48, timem=192).to('cuda'); "
+            "[out.update({f'{L}_{int(tr)}': (torch.manual_seed(5), mel.train(tr), mel(torch.from_numpy(G.frontend_inputs(dict(B=3, L=L, seed=81))).to('cuda')).cpu().numpy())[2]}) "
+            " for L in (320000, 160000, 48002, 31999) for tr in (False, True)]; np.savez(sys.argv[1], **out)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for knob in ("0", "1"):
+        f = str(tmp_path / f"mel{knob}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PA_MEL_PERSIST=knob), cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(f)))
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 8
+    for k in outs[0]:
+        assert outs[0][k].shape == outs[1][k].shape
+        assert float(np.abs(outs[0][k] - outs[1][k]).max()) < 2e-5, k
+
+
 def test_frontend_vs_oracle_random_augment():
     """train mode with random fmin/fmax and SpecAugment masks: same torch RNG stream as the oracle."""
     mel = passt_amd.AugmentMelSTFT(fmin_aug_range=10, fmax_aug_range=2000, freqm=48, timem=192).to(DEV).train()
