@@ -728,7 +728,7 @@ def run(args):
             "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
                        "grad_wire_dtype": args.comm_dtype if world > 1 else None,
-                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW)"
+                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW + weight staging)"
                                 + (", network forward + loss + backward + AdamW replayed from one captured hipGraph" if args.graph else "")
                                 if args.path == "trainstep" else
                                 "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
@@ -778,7 +778,7 @@ def run(args):
             # north_star: "rocprof-reported HBM GB/s for the front end": live number here, PMC traffic in profiles/
             if "mel" in side:
                 nm, msm, wm = side["mel"]
-                mt, mt_src = (committed_traffic("r05_mel_traffic.json", ["passt_amd/csrc/mel.hip"])
+                mt, mt_src = (committed_traffic("r06_mel_traffic.json", ["passt_amd/csrc/mel.hip"])
                               if (args.config == "c2" and B == 64) else (None, "only collected for config c2, B = 64"))
                 out["frontend"] = {"bound": "hbm", "kernel": "pa::mel_frontend_kernel (STFT + mel + log + SpecAugment, one launch)",
                                    "avg_us": round(1e3 * msm / nm, 2), "achieved": round(wm / msm / 1e6, 1), "peak": HBM_PEAK_GBPS,
@@ -788,7 +788,7 @@ def run(args):
             # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
             # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
             # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
-            traffic, traffic_src = (committed_traffic("r05_gemm_traffic.json", ["passt_amd/csrc/gemm.hip"])
+            traffic, traffic_src = (committed_traffic("r06_gemm_traffic.json", ["passt_amd/csrc/gemm.hip"])
                                     if (args.config == "c2" and B == 64 and args.precision == "bf16")
                                     else (None, "only collected for config c2, B = 64, bf16"))
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
