@@ -184,7 +184,10 @@ def test_frontend_persistent_form_equals_default(tmp_path):
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 8
     for k in outs[0]:
         assert outs[0][k].shape == outs[1][k].shape
-        assert float(np.abs(outs[0][k] - outs[1][k]).max()) < 2e-5, k
+        # the persistent form pre-emphasises with ONE fused multiply-add where stage 1 reads (the staged form rounds the product
+        # first): an ulp on the samples, which log(. + 1e-5) / 5 shows only in near-silent bins -- same bound as against the goldens
+        d = np.abs(outs[0][k] - outs[1][k])
+        assert float(d.max()) < 1e-3 and float(d.mean()) < 2e-6, (k, float(d.max()), float(d.mean()))
 
 
 def test_frontend_vs_oracle_random_augment():
