@@ -35,6 +35,7 @@ import contextlib
 import json
 import os
 import sys
+import threading
 import time
 import warnings
 
@@ -76,6 +77,7 @@ CONFIGS = {
 }
 
 
+DIAG_TIMEOUT_S = float(os.environ.get("PASST_AMD_BENCH_DIAG_TIMEOUT_S", "240"))   # N > 1: watchdog of the post-measurement diagnostics
 PROFILE_EVERY = 10     # timed steps between two steps that carry per-launch HIP events (two event records per launch cost the
                        # instrumented step ~6 %: r04 sampled 1 step in 5, r05 samples 1 in 10 -- steps 5 and 15 of the default 20)
 
@@ -564,6 +566,42 @@ def main():
         raise
 
 
+def multi_gpu_diagnostics(ts, x, y, barrier, args, rank, local_rank, world, dev):
+    """N > 1, after the timed region: one instrumented step (per-bucket HIP events), the same buckets all-reduced on an idle
+    GPU, what the communicator reports, every rank's device.  Returns (allreduce, rccl) on rank 0, (None, None) elsewhere."""
+    import torch.distributed as dist
+    if os.environ.get("PASST_AMD_BENCH_DIAG_FAIL_RANK") == str(rank):      # test hook (tests/test_gpu_ddp.py): this rank's diagnostics fail
+        raise RuntimeError("injected failure of the N > 1 diagnostics on this rank")
+    ts.reducer.start_timing()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ts.step(x, y)
+    barrier()
+    buckets = ts.reducer.timing_summary()
+    ts.reducer.timing = None
+    # the same buckets once more with the GPU otherwise idle: what the wire alone costs (the in-step figure above is
+    # launch -> released and therefore includes queueing behind the backward's kernels: it under-reports the bus)
+    idle = ts.reducer.measure_idle()
+    comm_info = ts.reducer.comm_info()
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device": f"cuda:{local_rank}", "name": props.name, "gcn_arch": getattr(props, "gcnArchName", None),
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "comm_nranks": comm_info.get("nranks"), "comm_rank": comm_info.get("rank")}
+    devices = [None] * world
+    dist.all_gather_object(devices, mine)
+    if rank != 0:
+        return None, None
+    allreduce = {"kind": "MEASURED on this run (one instrumented step after the timed region, rank 0)",
+                 "transport": args.transport, "wire_dtype": args.comm_dtype, "buckets": buckets,
+                 "bytes_per_step": sum(b["bytes"] for b in buckets),
+                 "exposed_wait_ms_per_step": round(sum(b["exposed_wait_ms"] for b in buckets), 4),
+                 "bus_GBps_min_max": [min(b["bus_GBps"] for b in buckets), max(b["bus_GBps"] for b in buckets)] if buckets else None,
+                 "idle": {"kind": "the same buckets all-reduced with the compute stream idle (best of 3 after a warm-up pass)",
+                          "buckets": idle, "ms_per_step": round(sum(b["ms"] for b in idle), 4),
+                          "bus_GBps_total": round(2.0 * (world - 1) / world * sum(b["bytes"] for b in idle)
+                                                  / max(sum(b["ms"] for b in idle), 1e-6) / 1e6, 1) if idle else None}}
+    return allreduce, dict(comm_info, ranks=devices)
+
+
 def run(args):
     if args.optimizer == "pa_adamw" and args.path != "autograd":
         raise ValueError("--optimizer pa_adamw is the autograd path's fused optimizer; TrainStep's adamw already is the fused kernel")
@@ -667,36 +705,14 @@ def run(args):
 
     # ---- outside the timed region -------------------------------------------------------------------------------
     # (a) N > 1: MEASURED per-bucket all-reduce (HIP events: launch -> released, and how long the compute stream was
-    #     blocked on it) of one extra instrumented step, next to the modelled curve
+    #     blocked on it) of one extra instrumented step, next to the modelled curve.  These diagnostics are more collectives
+    #     after the measurement is already complete: whatever happens in them (an exception on some rank, a peer that is
+    #     gone, a collective that never returns) must not cost the line -- they run under a watchdog, and a rank that fails
+    #     leaves without entering another collective (DIAG_TIMEOUT_S later the others print / exit without the diagnostics).
     allreduce = rccl = None
-    if world > 1:
-        ts.reducer.start_timing()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            ts.step(x, y)
-        barrier()
-        buckets = ts.reducer.timing_summary()
-        ts.reducer.timing = None
-        # the same buckets once more with the GPU otherwise idle: what the wire alone costs (the in-step figure above is
-        # launch -> released and therefore includes queueing behind the backward's kernels: it under-reports the bus)
-        idle = ts.reducer.measure_idle()
-        comm_info = ts.reducer.comm_info()
-        props = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "device": f"cuda:{local_rank}", "name": props.name, "gcn_arch": getattr(props, "gcnArchName", None),
-                "pci_bus_id": getattr(props, "pci_bus_id", None), "comm_nranks": comm_info.get("nranks"), "comm_rank": comm_info.get("rank")}
-        devices = [None] * world
-        dist.all_gather_object(devices, mine)
-        if rank == 0:
-            allreduce = {"kind": "MEASURED on this run (one instrumented step after the timed region, rank 0)",
-                         "transport": args.transport, "wire_dtype": args.comm_dtype, "buckets": buckets,
-                         "bytes_per_step": sum(b["bytes"] for b in buckets),
-                         "exposed_wait_ms_per_step": round(sum(b["exposed_wait_ms"] for b in buckets), 4),
-                         "bus_GBps_min_max": [min(b["bus_GBps"] for b in buckets), max(b["bus_GBps"] for b in buckets)] if buckets else None,
-                         "idle": {"kind": "the same buckets all-reduced with the compute stream idle (best of 3 after a warm-up pass)",
-                                  "buckets": idle, "ms_per_step": round(sum(b["ms"] for b in idle), 4),
-                                  "bus_GBps_total": round(2.0 * (world - 1) / world * sum(b["bytes"] for b in idle)
-                                                          / max(sum(b["ms"] for b in idle), 1e-6) / 1e6, 1) if idle else None}}
-            rccl = dict(comm_info, ranks=devices)
+    diag = {"error": None, "done": False}
+    report_lock = threading.Lock()
+
     # (b) the parity mode (exact-f32 MFMA, <= 3e-6 of the fp32 reference: the bound north_star states) trains this fast
     parity_clips = None
     if world == 1 and args.config == "c2" and args.precision == "bf16" and not args.no_cpu_baseline and args.path == "trainstep":
@@ -712,118 +728,164 @@ def run(args):
             parity_clips = round(3 * B / (time.perf_counter() - tp0), 1)
         net.precision = args.precision
 
-    if rank == 0:
-        clips = world * B * args.steps
-        value = clips / elapsed
-        Dm, depth, _ = cfgd["dims"]
-        gflop_clip = algorithmic_gflop_per_clip(cfgd["tokens"], Dm, depth, cfgd["kept"])
-        out = {
-            "metric": cfgd["metric"], "value": round(value, 2), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            **({"allreduce_bus_GBps_idle": allreduce["idle"]["bus_GBps_total"],
-                "allreduce_exposed_wait_ms_per_step": allreduce["exposed_wait_ms_per_step"],
-                "rccl_nranks": rccl.get("nranks")} if allreduce is not None else {}),
-            "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
-                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
-                       "grad_wire_dtype": args.comm_dtype if world > 1 else None,
-                       "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW + weight staging)"
-                                + (", network forward + loss + backward + AdamW replayed from one captured hipGraph" if args.graph else "")
-                                if args.path == "trainstep" else
-                                "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
-                                + {"adamw": "AdamW (multi-tensor default)", "sgd": "SGD", "pa_adamw": "AdamW replaced by passt_amd.optim.AdamW"}[args.optimizer]
-                                + (", my_mixup replaced by passt_amd.mixup.my_mixup" if args.mixup == "pa" else "")
-                                + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
-                       "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
-                                       if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
-                       "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
-            "algorithmic_gflop_per_clip": round(gflop_clip, 2),
-            "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
-            # the same on the FLOPs actually executed: the prefix-only tail skips part of the last block (exactly)
-            "mfma_frac_end_to_end_executed": round(value / world * (gflop_clip - skipped_tail_gflop_per_clip(cfgd["tokens"], Dm)) / 1e3
-                                                   / BF16_MFMA_PEAK_TFLOPS, 4),
-            "loss": round(loss_v, 6),
-        }
-        if prof:
-            n_prof_steps = len(profiled_steps(args.steps))
-            side = {}
-            for kind in ("attn_fwd", "attn_bwd", "mel"):
-                recs = prof.pop(kind, None)
-                if recs:
+    printed = {"done": False}
+
+    def report(allreduce, rccl):
+        """rank 0: the ONE JSON line (once: from the normal path, or from the watchdog if the N > 1 diagnostics hang)"""
+        with report_lock:
+            if printed["done"]:
+                return
+            printed["done"] = True
+            clips = world * B * args.steps
+            value = clips / elapsed
+            Dm, depth, _ = cfgd["dims"]
+            gflop_clip = algorithmic_gflop_per_clip(cfgd["tokens"], Dm, depth, cfgd["kept"])
+            out = {
+                "metric": cfgd["metric"], "value": round(value, 2), "unit": "clips/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                **({"allreduce_bus_GBps_idle": allreduce["idle"]["bus_GBps_total"],
+                    "allreduce_exposed_wait_ms_per_step": allreduce["exposed_wait_ms_per_step"],
+                    "rccl_nranks": rccl.get("nranks")} if allreduce is not None else {}),
+                "config": {"workload": cfgd["desc"].format(opt=args.optimizer), "baseline_config": args.config,
+                           "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}" + (" DRY RUN: all ranks on one device over gloo" if dry else ""),
+                           "grad_wire_dtype": args.comm_dtype if world > 1 else None,
+                           "path": ("TrainStep (explicit kernel sequence, fused mixup / loss / AdamW + weight staging)"
+                                    + (", network forward + loss + backward + AdamW replayed from one captured hipGraph" if args.graph else "")
+                                    if args.path == "trainstep" else
+                                    "autograd drop-in: torch mixup -> net(x) -> torch loss -> loss.backward() -> torch.optim."
+                                    + {"adamw": "AdamW (multi-tensor default)", "sgd": "SGD", "pa_adamw": "AdamW replaced by passt_amd.optim.AdamW"}[args.optimizer]
+                                    + (", my_mixup replaced by passt_amd.mixup.my_mixup" if args.mixup == "pa" else "")
+                                    + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
+                           "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
+                                           if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
+                           "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
+                "algorithmic_gflop_per_clip": round(gflop_clip, 2),
+                "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
+                # the same on the FLOPs actually executed: the prefix-only tail skips part of the last block (exactly, DESIGN 4.25)
+                "mfma_frac_end_to_end_executed": round(value / world * (gflop_clip - skipped_tail_gflop_per_clip(cfgd["tokens"], Dm)) / 1e3
+                                                       / BF16_MFMA_PEAK_TFLOPS, 4),
+                "loss": round(loss_v, 6),
+            }
+            if prof:
+                n_prof_steps = len(profiled_steps(args.steps))
+                side = {}
+                for kind in ("attn_fwd", "attn_bwd", "mel"):
+                    recs = prof.pop(kind, None)
+                    if recs:
+                        ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+                        side[kind] = (len(recs), ms, sum(w for _, _, w in recs))
+                tot_ms, tot_flop, n, per_kind = 0.0, 0.0, 0, {}
+                for kind, recs in prof.items():
                     ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-                    side[kind] = (len(recs), ms, sum(w for _, _, w in recs))
-            tot_ms, tot_flop, n, per_kind = 0.0, 0.0, 0, {}
-            for kind, recs in prof.items():
-                ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-                fl = sum(f for _, _, f in recs)
-                per_kind[kind] = {"launches": len(recs), "avg_us": round(1e3 * ms / len(recs), 2),
-                                  "tflops": round(fl / ms / 1e9, 1)}
-                tot_ms += ms
-                tot_flop += fl
-                n += len(recs)
-            achieved = tot_flop / tot_ms / 1e9
-            ms_step = 1e3 * elapsed / args.steps
-            # north_star: "MFMA utilisation for attention/MLP": the attention kernels, timed the same way in the same run
-            if "attn_fwd" in side and "attn_bwd" in side:
-                (nf, msf, wf), (nb, msb, wb) = side["attn_fwd"], side["attn_bwd"]
-                out["attention"] = {"bound": "mfma (co-bound by VALU: one exp per score, head dim 64)",
-                                    "fwd_avg_us": round(1e3 * msf / nf, 2), "fwd_tflops": round(wf / msf / 1e9, 1),
-                                    "bwd_avg_us": round(1e3 * msb / nb, 2), "bwd_tflops": round(wb / msb / 1e9, 1),
-                                    "achieved": round((wf + wb) / (msf + msb) / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": round((wf + wb) / (msf + msb) / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4),
-                                    "flops": "algorithmic: 4 N^2 64 per head forward, 10 N^2 64 backward (5 products); "
-                                             "last block: 2 queries only",
-                                    "time_share_of_step": round((msf + msb) / n_prof_steps / ms_step, 4)}
-            # north_star: "rocprof-reported HBM GB/s for the front end": live number here, PMC traffic in profiles/
-            if "mel" in side:
-                nm, msm, wm = side["mel"]
-                mt, mt_src = (committed_traffic("r06_mel_traffic.json", ["passt_amd/csrc/mel.hip"])
-                              if (args.config == "c2" and B == 64) else (None, "only collected for config c2, B = 64"))
-                out["frontend"] = {"bound": "hbm", "kernel": "pa::mel_frontend_kernel (STFT + mel + log + SpecAugment, one launch)",
-                                   "avg_us": round(1e3 * msm / nm, 2), "achieved": round(wm / msm / 1e6, 1), "peak": HBM_PEAK_GBPS,
-                                   "unit": "GB/s", "frac": round(wm / msm / 1e6 / HBM_PEAK_GBPS, 4),
-                                   "algorithmic_bytes_per_launch": round(wm / nm), "traffic": mt, "traffic_source": mt_src,
-                                   "time_share_of_step": round(msm / n_prof_steps / ms_step, 4)}
-            # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
-            # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
-            # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
-            traffic, traffic_src = (committed_traffic("r06_gemm_traffic.json", ["passt_amd/csrc/gemm.hip"])
-                                    if (args.config == "c2" and B == 64 and args.precision == "bf16")
-                                    else (None, "only collected for config c2, B = 64, bf16"))
-            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                               "algorithmic_flop_per_launch": round(tot_flop / n),
-                               "kernel": "GEMM family pa::gemm_nt_stagger_kernel / gemm_nt_kernel / gemm_tn_stagger_kernel <bf16> "
-                                         "(all epilogues + weight gradients; 2*M*N*K algorithmic FLOPs per launch)",
-                               "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
-                               "sampling": f"HIP events around every GEMM launch of 1 timed step in {PROFILE_EVERY} (steps {', '.join(map(str, list(profiled_steps(args.steps))[:3]))}{', ...' if len(profiled_steps(args.steps)) > 3 else ''})",
-                               "gemm_time_share_of_step": round(tot_ms / n_prof_steps / ms_step, 4),
-                               "per_epilogue": per_kind}
-        # multi-GPU: SCALE is measured by the driver when it has an 8-GPU node; what can be said from ONE GPU is a model
-        bus_eff, bus_src = 0.35, "35 % (an ASSUMED RCCL bus efficiency: no N > 1 measurement in this run)"
-        idle_bus = (allreduce or {}).get("idle", {}).get("bus_GBps_total") if not dry else None
-        if idle_bus:
-            bus_eff = idle_bus / (min(world - 1, 7) * 153.0)
-            bus_src = (f"{100 * bus_eff:.1f} % = this run's own idle all-reduce of the same buckets ({idle_bus} GB/s bus bandwidth at "
-                       f"N = {world}, allreduce_measured.idle) over the link peak")
-        out["scaling_model"] = {"kind": "MODELLED, not measured" + (" (wire term from this run's measured bus bandwidth)" if idle_bus else ""),
-                                "inputs": "this run's ms_per_step, the reducer's bucket bytes (one bucket per block, launched from the "
-                                f"backward), min(N-1, 7) xGMI links x 153 GB/s at {bus_src}, GEMM slow-down next to a co-running "
-                                "whole-CU kernel from profiles/r04_copersist_probe.txt (worst case: +28 %)",
-                                "bus_efficiency": round(bus_eff, 4),
-                                "bucket_MB": {str(k): round(v / 1e6, 2) for k, v in ts.reducer.bucket_bytes().items()},
-                                "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes(), bus_eff=bus_eff)}
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            out["cpu_baseline"] = cpu_baseline()
-            out["cpu_baseline_forward"] = cpu_baseline_forward()
-        if parity_clips is not None:
-            out["parity_mode_clips_s"] = parity_clips     # same step, precision="fp32": what meets the <= 1e-3 parity bound
-        if allreduce is not None:
-            out["allreduce_measured"] = allreduce
-            out["rccl"] = rccl
-        print(json.dumps(out), flush=True)
+                    fl = sum(f for _, _, f in recs)
+                    per_kind[kind] = {"launches": len(recs), "avg_us": round(1e3 * ms / len(recs), 2),
+                                      "tflops": round(fl / ms / 1e9, 1)}
+                    tot_ms += ms
+                    tot_flop += fl
+                    n += len(recs)
+                achieved = tot_flop / tot_ms / 1e9
+                ms_step = 1e3 * elapsed / args.steps
+                # north_star: "MFMA utilisation for attention/MLP": the attention kernels, timed the same way in the same run
+                if "attn_fwd" in side and "attn_bwd" in side:
+                    (nf, msf, wf), (nb, msb, wb) = side["attn_fwd"], side["attn_bwd"]
+                    out["attention"] = {"bound": "mfma (co-bound by VALU: one exp per score, head dim 64)",
+                                        "fwd_avg_us": round(1e3 * msf / nf, 2), "fwd_tflops": round(wf / msf / 1e9, 1),
+                                        "bwd_avg_us": round(1e3 * msb / nb, 2), "bwd_tflops": round(wb / msb / 1e9, 1),
+                                        "achieved": round((wf + wb) / (msf + msb) / 1e9, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": round((wf + wb) / (msf + msb) / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                        "flops": "algorithmic: 4 N^2 64 per head forward, 10 N^2 64 backward (5 products); "
+                                                 "last block: 2 queries only",
+                                        "time_share_of_step": round((msf + msb) / n_prof_steps / ms_step, 4)}
+                # north_star: "rocprof-reported HBM GB/s for the front end": live number here, PMC traffic in profiles/
+                if "mel" in side:
+                    nm, msm, wm = side["mel"]
+                    mt, mt_src = (committed_traffic("r06_mel_traffic.json", ["passt_amd/csrc/mel.hip"])
+                                  if (args.config == "c2" and B == 64) else (None, "only collected for config c2, B = 64"))
+                    out["frontend"] = {"bound": "hbm", "kernel": "pa::mel_frontend_kernel (STFT + mel + log + SpecAugment, one launch)",
+                                       "avg_us": round(1e3 * msm / nm, 2), "achieved": round(wm / msm / 1e6, 1), "peak": HBM_PEAK_GBPS,
+                                       "unit": "GB/s", "frac": round(wm / msm / 1e6 / HBM_PEAK_GBPS, 4),
+                                       "algorithmic_bytes_per_launch": round(wm / nm), "traffic": mt, "traffic_source": mt_src,
+                                       "time_share_of_step": round(msm / n_prof_steps / ms_step, 4)}
+                # HBM traffic per launch of the same kernel family: PMC counters cannot be read from inside this
+                # process; they are collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes)
+                # over this very command and committed (tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json)
+                traffic, traffic_src = (committed_traffic("r06_gemm_traffic.json", ["passt_amd/csrc/gemm.hip"])
+                                        if (args.config == "c2" and B == 64 and args.precision == "bf16")
+                                        else (None, "only collected for config c2, B = 64, bf16"))
+                out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                                   "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                                   "algorithmic_flop_per_launch": round(tot_flop / n),
+                                   "kernel": "GEMM family pa::gemm_nt_stagger_kernel / gemm_nt_kernel / gemm_tn_stagger_kernel <bf16> "
+                                             "(all epilogues + weight gradients; 2*M*N*K algorithmic FLOPs per launch)",
+                                   "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2),
+                                   "sampling": f"HIP events around every GEMM launch of 1 timed step in {PROFILE_EVERY} (steps {', '.join(map(str, list(profiled_steps(args.steps))[:3]))}{', ...' if len(profiled_steps(args.steps)) > 3 else ''})",
+                                   "gemm_time_share_of_step": round(tot_ms / n_prof_steps / ms_step, 4),
+                                   "per_epilogue": per_kind}
+            # multi-GPU: SCALE is measured by the driver when it has an 8-GPU node; what can be said from ONE GPU is a model
+            bus_eff, bus_src = 0.35, "35 % (an ASSUMED RCCL bus efficiency: no N > 1 measurement in this run)"
+            idle_bus = (allreduce or {}).get("idle", {}).get("bus_GBps_total") if not dry else None
+            if idle_bus:
+                bus_eff = idle_bus / (min(world - 1, 7) * 153.0)
+                bus_src = (f"{100 * bus_eff:.1f} % = this run's own idle all-reduce of the same buckets ({idle_bus} GB/s bus bandwidth at "
+                           f"N = {world}, allreduce_measured.idle) over the link peak")
+            out["scaling_model"] = {"kind": "MODELLED, not measured" + (" (wire term from this run's measured bus bandwidth)" if idle_bus else ""),
+                                    "inputs": "this run's ms_per_step, the reducer's bucket bytes (one bucket per block, launched from the "
+                                    f"backward), min(N-1, 7) xGMI links x 153 GB/s at {bus_src}, GEMM slow-down next to a co-running "
+                                    "whole-CU kernel from profiles/r04_copersist_probe.txt (worst case: +28 %)",
+                                    "bus_efficiency": round(bus_eff, 4),
+                                    "bucket_MB": {str(k): round(v / 1e6, 2) for k, v in ts.reducer.bucket_bytes().items()},
+                                    "n_gpus": modelled_scaling(1e3 * elapsed / args.steps, ts.reducer.bucket_bytes(), bus_eff=bus_eff)}
+            if world == 1 and not args.no_cpu_baseline and args.config == "c2":
+                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline_forward"] = cpu_baseline_forward()
+            if parity_clips is not None:
+                out["parity_mode_clips_s"] = parity_clips     # same step, precision="fp32": what meets the <= 1e-3 parity bound
+            if allreduce is not None:
+                out["allreduce_measured"] = allreduce
+                out["rccl"] = rccl
+            if diag["error"]:
+                out["multi_gpu_diagnostics_error"] = diag["error"]
+            print(json.dumps(out), flush=True)
+
+    def watchdog_fire():
+        if diag["done"]:
+            return
+        diag["error"] = (f"the N > 1 diagnostics after the timed region did not finish within {DIAG_TIMEOUT_S} s on rank {rank}; "
+                         "value / ms_per_step are the completed measurement")
+        if rank == 0:
+            try:
+                torch.cuda.set_device(local_rank)
+                report(None, None)
+            finally:
+                os._exit(0)
+        os._exit(0)
+
+    watchdog = None
+    if world > 1:
+        watchdog = threading.Timer(DIAG_TIMEOUT_S if rank == 0 else DIAG_TIMEOUT_S + 20, watchdog_fire)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            allreduce, rccl = multi_gpu_diagnostics(ts, x, y, barrier, args, rank, local_rank, world, dev)
+        except Exception as e:      # noqa: BLE001 -- diagnostics only
+            diag["error"] = f"{type(e).__name__}: {e}"[:300]
+            allreduce = rccl = None
+            if rank != 0:
+                # no further collective on this rank (the peers would wait for it in vain): leave; rank 0's watchdog prints
+                print(f"[bench rank {rank}] N > 1 diagnostics failed: {diag['error']}", file=sys.stderr, flush=True)
+                os._exit(0)
+    diag["done"] = True
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        report(allreduce, rccl)
+    if world > 1 and diag["error"]:
+        # the ranks are no longer in step with each other: no closing barrier / communicator teardown (they could hang)
+        sys.stdout.flush()
+        os._exit(0)
     ts.close()
     if world > 1:
         dist.barrier()

@@ -155,6 +155,22 @@ def import_reference_file(relpath: str):
 
     stubs = {"ba3l": _mod("ba3l"), "ba3l.ingredients": _mod("ba3l.ingredients"),
              "ba3l.ingredients.ingredient": _mod("ba3l.ingredients.ingredient", Ingredient=Ingredient)}
+    if "pytorch_lightning" not in sys.modules:
+        # helpers/swa_callback.py:25-27 subclasses Lightning's Callback and raises its MisconfigurationException; Lightning is
+        # not installed here.  The callback's arithmetic (update_parameters / avg_fn, :246-268) and its epoch schedule
+        # (on_train_epoch_start, :161-197) touch nothing else of Lightning, so a bare base class is all the file needs to run.
+        class Callback:
+            pass
+
+        class MisconfigurationException(Exception):
+            pass
+
+        pl = _mod("pytorch_lightning", LightningModule=object, Trainer=object)
+        pl.callbacks = _mod("pytorch_lightning.callbacks", Callback=Callback)
+        pl.utilities = _mod("pytorch_lightning.utilities")
+        pl.utilities.exceptions = _mod("pytorch_lightning.utilities.exceptions", MisconfigurationException=MisconfigurationException)
+        stubs.update({k: sys.modules[k] for k in ("pytorch_lightning", "pytorch_lightning.callbacks", "pytorch_lightning.utilities",
+                                                  "pytorch_lightning.utilities.exceptions")})
     try:
         spec = importlib.util.spec_from_file_location("_ref_file_" + relpath.replace("/", "_").replace(".", "_"),
                                                       os.path.join(REFERENCE_ROOT, relpath))

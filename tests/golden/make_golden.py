@@ -242,6 +242,68 @@ def gen_wave_case():
     print("wave_augment", np.stack(out).shape, float(np.abs(np.stack(out)).max()))
 
 
+SWA_CASE = dict(seed=31, shapes=[(5, 7), (11,), (2, 3, 4)], max_epochs=12,
+                runs=[dict(swa_epoch_start=4, swa_freq=3), dict(swa_epoch_start=0.5, swa_freq=3), dict(swa_epoch_start=1, swa_freq=5)])
+
+
+def swa_snapshots(case):
+    """[max_epochs][n] f32: the network's parameters (flat, parameter order) at the start of every epoch"""
+    n = sum(int(np.prod(s)) for s in case["shapes"])
+    return np.stack([detgen.uniform(case["seed"], f"epoch{e}", (n,), -1.0, 1.0).astype(np.float32) + 0.1 * e
+                     for e in range(case["max_epochs"])])
+
+
+def gen_swa_case(out_dir=HERE):
+    """Runs the REAL helpers/swa_callback.py (StochasticWeightAveraging: setup, on_fit_start, on_train_epoch_start ->
+    update_parameters / avg_fn, on_validation_epoch_start) over SWA_CASE's epochs with a stand-in trainer; Lightning's Callback
+    base class is stubbed (oracle/ref_import.py), everything the callback computes is its own code."""
+    import contextlib, io, warnings
+    mod = ref_import.import_reference_file("helpers/swa_callback.py")
+    c = SWA_CASE
+    snaps = swa_snapshots(c)
+    out = {}
+    for ri, run in enumerate(c["runs"]):
+        net = torch.nn.Module()
+        for i, shp in enumerate(c["shapes"]):
+            net.register_parameter(f"p{i}", torch.nn.Parameter(torch.zeros(shp)))
+
+        class PlModule(torch.nn.Module):
+            device = torch.device("cpu")
+
+        plm = PlModule()
+        plm.net = net
+
+        class Trainer:
+            pass
+
+        tr = Trainer()
+        tr.max_epochs, tr.current_epoch, tr.lr_scheduler_configs = c["max_epochs"], 0, []
+        tr.optimizers = [torch.optim.SGD(net.parameters(), lr=0.1)]
+        cb = mod.StochasticWeightAveraging(swa_epoch_start=run["swa_epoch_start"], swa_freq=run["swa_freq"])
+        avgs, counts, flags = [], [], []
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cb.setup(tr, plm, "fit")
+            cb.on_fit_start(tr, plm)
+            for e in range(c["max_epochs"]):
+                tr.current_epoch = e
+                off = 0
+                with torch.no_grad():
+                    for p in net.parameters():
+                        p.copy_(torch.from_numpy(snaps[e, off:off + p.numel()].copy()).view(p.shape))
+                        off += p.numel()
+                cb.on_train_epoch_start(tr, plm)
+                cb.on_validation_epoch_start(tr, plm)
+                started = hasattr(cb, "n_averaged")
+                avgs.append(torch.cat([p.detach().reshape(-1) for p in cb._average_model.parameters()]).numpy().copy()
+                            if started else np.zeros(snaps.shape[1], np.float32))
+                counts.append(int(cb.n_averaged) if started else 0)
+                flags.append(bool(plm.do_swa))
+        out[f"run{ri}.avg"], out[f"run{ri}.n_averaged"], out[f"run{ri}.do_swa"] = np.stack(avgs), np.array(counts), np.array(flags)
+        print("swa run", ri, run, "updates at", [e for e, f in enumerate(flags) if f], "n_averaged", counts[-1])
+    np.savez_compressed(os.path.join(out_dir, "swa_callback.npz"), **out)
+
+
 def gen_rng_kat():
     """SURVEY.md App. C KAT: the index path on torch CPU."""
     torch.manual_seed(123)
@@ -254,6 +316,9 @@ def gen_rng_kat():
 if __name__ == "__main__":
     assert ref_import.reference_available(), "needs /root/reference"
     torch.set_num_threads(min(32, os.cpu_count()))
+    if len(sys.argv) > 1 and sys.argv[1] == "swa":       # the SWA callback run live (r06)
+        gen_swa_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the full-size cases (minutes of CPU time); big <name>: one of them
         for n, c in BIG_CASES.items():
             if len(sys.argv) < 3 or n in sys.argv[2:]:
@@ -275,3 +340,4 @@ if __name__ == "__main__":
         gen_frontend_case(n, c)
     gen_rng_kat()
     gen_wave_case()
+    gen_swa_case()

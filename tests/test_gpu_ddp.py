@@ -197,6 +197,32 @@ def test_bench_multi_rank_dry_run():
     assert all(b["in_flight_ms"] > 0 and b["exposed_wait_ms"] >= 0 for b in ar["buckets"])
 
 
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_bench_multi_rank_line_survives_failing_diagnostics(fail_rank):
+    """The N > 1 diagnostics (instrumented step, idle all-reduces, device gather) run AFTER the measurement is complete: a rank
+    whose diagnostics fail (injected) must not cost the line.  The failing rank leaves without another collective; the peers'
+    watchdog (here 15 s) releases them; rank 0 prints value / ms_per_step with `multi_gpu_diagnostics_error`; every rank exits 0."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PASST_AMD_BENCH_DRY_GLOO="1", PASST_AMD_BENCH_DIAG_FAIL_RANK=str(fail_rank),
+                   PASST_AMD_BENCH_DIAG_TIMEOUT_S="15")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        outs.append((p.returncode, o.decode(), e.decode()[-1500:]))
+    assert all(rc == 0 for rc, _, _ in outs), outs
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "multi_gpu_diagnostics_error" in d and "allreduce_measured" not in d
+
+
 def test_bench_sweep_dry_run():
     """`python bench.py --sweep-gpus 1,2` -- the single command that yields the weak-scaling curve on a multi-GPU node -- on the one
     GPU of a test box: N = 1 for real, N = 2 as two self-launched ranks on device 0 over gloo (PASST_AMD_BENCH_DRY_GLOO=1).  One

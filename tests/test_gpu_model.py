@@ -776,6 +776,28 @@ def test_swa_matches_reference_update_rule():
         assert torch.equal(p.detach().double().cpu(), s), name
 
 
+def test_swa_matches_reference_callback_fixture(golden_dir):
+    """schedule.SWA (pa_swa_update on the flat buffer + the callback's epoch schedule) against tests/golden/swa_callback.npz: the
+    averaged parameters, counts and do_swa flags the reference's own helpers/swa_callback.py produced on the same per-epoch
+    snapshots (make_golden.gen_swa_case runs the callback live; the CPU suite regenerates the file bit for bit)."""
+    import types
+    from passt_amd.schedule import SWA
+    gold = dict(np.load(os.path.join(golden_dir, "swa_callback.npz")))
+    c = G.SWA_CASE
+    snaps = G.swa_snapshots(c)
+    for ri, run in enumerate(c["runs"]):
+        ts = types.SimpleNamespace(flat_p=torch.zeros(snaps.shape[1], device=DEV), named=[])
+        swa = SWA(ts, **run)
+        for e in range(c["max_epochs"]):
+            ts.flat_p.copy_(torch.from_numpy(snaps[e]))
+            did = swa.on_train_epoch_start(e, c["max_epochs"])
+            assert did == bool(gold[f"run{ri}.do_swa"][e]) and swa.n_averaged == int(gold[f"run{ri}.n_averaged"][e]), (ri, e)
+            if swa.n_averaged:
+                want = gold[f"run{ri}.avg"][e]
+                d = float(np.abs(swa.avg.cpu().numpy() - want).max())
+                assert d <= 2.4e-7 * float(np.abs(want).max()), (ri, e, d)        # one ulp: x * (1 / (n + 1)) against x / (n + 1)
+
+
 # ---- r02: full-size goldens produced by the REAL reference (tests/golden/make_golden.py big) ---------------------------
 @pytest.mark.parametrize("name", list(G.BIG_CASES))
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

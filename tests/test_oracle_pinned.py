@@ -340,6 +340,34 @@ def test_lr_schedule_matches_reference_ramp():
             assert f(e) == pytest.approx(g(e), rel=1e-12, abs=1e-15)
 
 
+def test_swa_schedule_and_fixture_pinned_to_live_callback(golden_dir, tmp_path, monkeypatch):
+    """tests/golden/swa_callback.npz is the output of the reference's own helpers/swa_callback.py (regenerated here bit for bit
+    where /root/reference exists); passt_amd.schedule.SWA's epoch schedule (when a snapshot is averaged in, when the count
+    restarts) against it on the CPU -- the averaging kernel itself is the GPU test test_swa_matches_reference_callback_fixture,
+    so here pa_swa_update is replaced by a counter."""
+    import types
+    from passt_amd import schedule
+    gold = _load(golden_dir, "swa_callback")
+    c = G.SWA_CASE
+    if ref_import.reference_available():
+        G.gen_swa_case(str(tmp_path))
+        fresh = dict(np.load(os.path.join(str(tmp_path), "swa_callback.npz")))
+        assert fresh.keys() == gold.keys()
+        for k in gold:
+            assert np.array_equal(fresh[k], gold[k]), k
+    monkeypatch.setattr(schedule.ops, "swa_update", lambda avg, p, n: None)
+    for ri, run in enumerate(c["runs"]):
+        swa = schedule.SWA(types.SimpleNamespace(flat_p=torch.zeros(4), named=[]), **run)
+        for e in range(c["max_epochs"]):
+            did = swa.on_train_epoch_start(e, c["max_epochs"])
+            assert did == bool(gold[f"run{ri}.do_swa"][e]), (ri, e)
+            assert swa.n_averaged == int(gold[f"run{ri}.n_averaged"][e]), (ri, e)
+    with pytest.raises(ValueError):
+        schedule.SWA(types.SimpleNamespace(flat_p=torch.zeros(4), named=[]), swa_epoch_start=0)
+    with pytest.raises(ValueError):
+        schedule.SWA(types.SimpleNamespace(flat_p=torch.zeros(4), named=[]), swa_epoch_start=1.5)
+
+
 def test_wave_oracle_pinned_to_reference_outputs():
     """oracle/wave_oracle.py vs tests/golden/wave_augment.npz (outputs of the reference's own pad_or_truncate /
     pydub_augment / roll_func / MixupDataset bodies, see make_golden.gen_wave_case)."""
