@@ -40,6 +40,23 @@ namespace pa {
 #ifndef PA_ATTN_PK
 #define PA_ATTN_PK 0
 #endif
+// Cache policy of the result stores (A/B build knob, round 6 sweep profiles/r06_cache_policy.txt): 1 = non-temporal
+#ifndef PA_ATTN_FUSED_NT_LD
+#define PA_ATTN_FUSED_NT_LD 0      // 2: the single-pass backward stages K and the Q / dO tiles (each read by ONE workgroup) non-temporally
+#endif
+#ifndef PA_ATTN_NT_KV
+#define PA_ATTN_NT_KV 0            // 2: streamed tiles of the forward / two-kernel backward non-temporally
+#endif
+#ifndef PA_ATTN_NT_ST
+#define PA_ATTN_NT_ST 0
+#endif
+template <typename V> __device__ __forceinline__ void attn_store(V* p, const V& v) {
+#if PA_ATTN_NT_ST
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 static constexpr int HD = 64;       // head dim (all PaSST archs: 768/12, 1024/16, 384/6, 128/2)
 static constexpr int TROWS = 64;    // streamed rows per LDS tile
 static constexpr float LOG2E = 1.4426950408889634f;
@@ -150,7 +167,7 @@ __device__ __forceinline__ void stage_tile_off(char* lds, const char* tile_base,
 #pragma unroll
     for (int i = 0; i < LaneOff<T>::PER_WAVE; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile_base + voff[i]),
-                                         (__attribute__((address_space(3))) void*)(lds + (wave * LaneOff<T>::PER_WAVE + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * LaneOff<T>::PER_WAVE + i) * 1024), 16, 0, PA_ATTN_NT_KV);
 }
 template <typename T> __device__ __forceinline__ void lane_offsets(LaneOff<T>& lo, int lane) {
     const int row = lane & 31, h = lane >> 5;
@@ -219,7 +236,7 @@ __device__ __forceinline__ void store_rows_direct(const f32x16 (&acc)[2], float 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul};
-                if (ok) *(f32x4*)(rowp + db * 32 + 8 * g + 4 * h) = v;
+                if (ok) attn_store((f32x4*)(rowp + db * 32 + 8 * g + 4 * h), v);
             }
         } else {
 #pragma unroll
@@ -235,7 +252,7 @@ __device__ __forceinline__ void store_rows_direct(const f32x16 (&acc)[2], float 
                 const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                if (ok) *(u32x4*)(rowp + db * 32 + 16 * gp + 8 * h) = v;
+                if (ok) attn_store((u32x4*)(rowp + db * 32 + 16 * gp + 8 * h), v);
             }
         }
     }
@@ -932,7 +949,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
             const int row = rq * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz_f128(row);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gK + (int64_t)min(row, N - 1) * ldbq + c * 16),
-                                             (__attribute__((address_space(3))) void*)(sK + rq * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sK + rq * 1024), 16, 0, PA_ATTN_FUSED_NT_LD);
         }
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -948,7 +965,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         if (W16 && wave >= 8) return;
         const int grow = min(t * 32 + st_row, N - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st_src + (int64_t)grow * st_ldb + st_chunk),
-                                         (__attribute__((address_space(3))) void*)(sStage + (t & 1) * F_STAGE + st_tensor * 4096 + st_piece * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sStage + (t & 1) * F_STAGE + st_tensor * 4096 + st_piece * 1024), 16, 0, PA_ATTN_FUSED_NT_LD);
     };
     stage(0);
     const int kbase0 = wave * (32 * NKB);
@@ -1235,8 +1252,8 @@ __global__ __launch_bounds__(W16 ? 1024 : 512) __attribute__((amdgpu_waves_per_e
         const int q = t * 32 + q16 * 16 + (lane & 15);
         if (q < N) {
             const bf16x2 lo2 = {(bf16)(acc[0] * scale), (bf16)(acc[1] * scale)}, hi2 = {(bf16)(acc[2] * scale), (bf16)(acc[3] * scale)};
-            *(u32x2_t*)(dqkv + ((int64_t)b * N + q) * lddqkv + h * HD + d16 * 16 + 4 * (lane >> 4)) =
-                u32x2_t{__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2)};
+            attn_store((u32x2_t*)(dqkv + ((int64_t)b * N + q) * lddqkv + h * HD + d16 * 16 + 4 * (lane >> 4)),
+                       u32x2_t{__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2)});
         }
     };
 

@@ -54,7 +54,76 @@ static constexpr int PROBE_SLOTS = 512;
 #define PA_PROBE_FLAG(a, bit) 0
 #endif
 
-
+// ---- Cache policy of the step's GEMM memory instructions, per role (round 6, profiles/r06_cache_policy.txt) ----------------
+// The `aux` immediate of the buffer / LDS-DMA instructions: 1 = sc0, 2 = nt (non-temporal), 16 = sc1.  An XCD's L2 is 4 MiB;
+// the weights of one GEMM are 1.2 - 4.7 MB and are re-read by every row band, the activation tiles by N / 256 column tiles,
+// while every output line and every epilogue operand row is touched exactly once.  With the default policy those single-use
+// lines push the re-used ones out of the L2 (and the 256 MiB Infinity Cache): marking them non-temporal is worth 1.5 - 2.4 % of
+// the whole training step (config #2, five boxes, ABBA order: 22.39 -> 21.98, 21.78 -> 21.46, 21.73 -> 21.27 ms), e.g. the fc2
+// + residual GEMM 106 -> 97 us, fc1 + GELU 171 -> 160 us.  What the sweep settled, role by role:
+//   nt  fc1's blocked pre-activation (written in the forward, next read in the backward)                      PA_AUX_ST_PRE
+//   nt  the bf16 outputs of the STORE / GELU / GELU' epilogues (full 128-byte lines per 8 lanes)               PA_AUX_ST_OUT
+//   nt  the epilogue operand rows read once (residual rows, pre-activation blocks)                            PA_AUX_LD_AUX
+//   nt  the A operand of the residual GEMMs (N = D: a tile is read by D / 256 column tiles only, and fc2's
+//       W^T alone is 4.7 MB)                                                                                  PA_AUX_DMA_A_RESID
+//   nt  the split-K slabs when the finishing reduction reads them (each once)                                 PA_NT_LD_SLAB
+//   default: the f32 residual-stream output (nt: the LayerNorm behind it reads HBM, +0.5 %), the A operand of every other GEMM
+//       (nt: fc1 + GELU 170 -> 188 us), the weights (nt: +4 % on the step), the weight-gradient operands and slab stores
+//       (+- 0), sc1 instead of nt on the outputs (half the gain), nt on the A operand of plain-store GEMMs with N = D (+0.5 %).
+// -DPA_NO_CACHE_POLICY builds the library with the default policy everywhere (A/B: tools/build_variant.sh).
+#ifdef PA_NO_CACHE_POLICY
+#define PA_CP(x) 0
+#else
+#define PA_CP(x) x
+#endif
+#ifndef PA_AUX_ST_PRE
+#define PA_AUX_ST_PRE PA_CP(2)
+#endif
+#ifndef PA_AUX_ST_OUT
+#define PA_AUX_ST_OUT PA_CP(2)
+#endif
+#ifndef PA_AUX_ST_RES
+#define PA_AUX_ST_RES 0
+#endif
+#ifndef PA_AUX_LD_AUX
+#define PA_AUX_LD_AUX PA_CP(2)
+#endif
+#ifndef PA_AUX_LD_PRE
+#define PA_AUX_LD_PRE PA_AUX_LD_AUX      // ... the GELU' epilogue's pre-activation only
+#endif
+#ifndef PA_AUX_LD_RES
+#define PA_AUX_LD_RES PA_AUX_LD_AUX      // ... the residual rows only
+#endif
+#ifndef PA_AUX_DMA_A
+#define PA_AUX_DMA_A 0         // LDS-DMA of the A operand (activations) of the role-split NT kernel
+#endif
+#ifndef PA_AUX_DMA_A_RESID
+#define PA_AUX_DMA_A_RESID PA_CP(2)      // ... in the residual GEMMs
+#endif
+#ifndef PA_NT_A_STORE_MAXN
+#define PA_NT_A_STORE_MAXN 0   // plain-store GEMMs with N <= this read their A operand non-temporally too (input gradients: N = D)
+#endif
+#ifndef PA_NT_LD_SLAB
+#define PA_NT_LD_SLAB PA_CP(1) // the finishing reduction reads the slabs (each once) non-temporally
+#endif
+#ifndef PA_NT_STORE_MAXN
+#define PA_NT_STORE_MAXN 0     // > 0: the plain-store epilogue uses PA_AUX_ST_OUT only when N <= this, the default policy above
+#endif
+#ifndef PA_NT_ST_SLAB
+#define PA_NT_ST_SLAB 0        // 1: split-K partial slabs (weight gradients, small-M NT GEMMs) leave as non-temporal stores
+#endif
+#ifndef PA_AUX_DMA_B
+#define PA_AUX_DMA_B 0         // LDS-DMA of the B operand (weights)
+#endif
+#ifndef PA_AUX_DMA_TN
+#define PA_AUX_DMA_TN 0        // LDS-DMA of both operands of the weight-gradient kernel
+#endif
+#ifndef PA_AUX_DMA_TN_A
+#define PA_AUX_DMA_TN_A PA_AUX_DMA_TN      // ... of dY only
+#endif
+#ifndef PA_AUX_DMA_TN_B
+#define PA_AUX_DMA_TN_B PA_AUX_DMA_TN      // ... of X only
+#endif
 
 // Shared epilogue: the TM x 2 MFMA accumulators of this wave (TM*32 x 64 outputs at rows m0 + wr*TM*32,
 // columns n0 + wc*64) -> per-wave LDS slab [32][68] -> 8-wide row vectors with the fused epilogue math.
@@ -270,8 +339,11 @@ __device__ __forceinline__ void gemm_epilogue_f32_direct(const pa_gemm_args& a, 
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + b2[j] + (RES ? x[u % DEPTH][r] : 0.f);
             if (u + DEPTH < U) load_unit(u % DEPTH, u + DEPTH);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                *(float*)(obase + (vo + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo4 + j * 128)) = v[r];
+            for (int r = 0; r < 16; ++r) {
+                float* dstp = (float*)(obase + (vo + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo4 + j * 128));
+                if (PA_NT_ST_SLAB && !RES) __builtin_nontemporal_store(v[r], dstp);
+                else *dstp = v[r];
+            }
         }
     } else {   // edge tiles and the row-remapped (patch embedding) form: per-element checks
 #pragma unroll
@@ -406,19 +478,19 @@ template <int EPI, int TM, bool BLK = false> struct V2Aux {
         if constexpr (BLK) {       // blocked layout: the four 1 KiB quarters of pass i's block -> v[slot*4 + q]
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                v[slot * 4 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)q * 1024u, blk_base + (uint32_t)i * blk_pitch, 0);
+                v[slot * 4 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)q * 1024u, blk_base + (uint32_t)i * blk_pitch, PA_AUX_LD_PRE);
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    v[slot * 4 + t * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(i * 32 + 16 * t + q) * ld, 0, 0);
+                    v[slot * 4 + t * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(i * 32 + 16 * t + q) * ld, 0, PA_AUX_LD_PRE);
         }
     }
     // RESID: rows it*4 + (lane>>4) of half pass hp  ->  v[slot*4 + it]
     __device__ __forceinline__ void load_half(int slot, int hp) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) v[slot * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(hp * 16 + it * 4) * ld, 0, 0);
+        for (int it = 0; it < 4; ++it) v[slot * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs + (uint32_t)(hp * 16 + it * 4) * ld, 0, PA_AUX_LD_RES);
     }
 };
 
@@ -534,7 +606,7 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
             for (int q = 0; q < 4; ++q) {
                 const u32x4 d = {pk[q >> 1][4 * (q & 1)], pk[q >> 1][4 * (q & 1) + 1], pk[q >> 1][4 * (q & 1) + 2], pk[q >> 1][4 * (q & 1) + 3]};
                 __builtin_amdgcn_raw_buffer_store_b128(d, brs, (PA_PROBE_FLAG(a, 0) ? V2_OOB : (uint32_t)lane * 16u) + (uint32_t)q * 1024u,
-                                                       bbase + (uint32_t)i * bpitch, 0);
+                                                       bbase + (uint32_t)i * bpitch, PA_AUX_ST_PRE);
             }
         }
 #pragma unroll
@@ -554,8 +626,13 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                 const u32x4 hi = {perm_hi16(d0[1], d0[0]), perm_hi16(d0[3], d0[2]), perm_hi16(d1[1], d1[0]), perm_hi16(d1[3], d1[2])};
                 const uint32_t ldb = o ? ld2b : ld2;
                 const uint32_t off = (PA_PROBE_FLAG(a, 0) ? V2_OOB : (o ? vo2 : vo)) + (uint32_t)(i * 32 + 16 * t) * ldb;
-                __builtin_amdgcn_raw_buffer_store_b128(lo, o ? ors2 : ors, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(hi, o ? ors2 : ors, off + ldb, 0, 0);
+                if (EPI == PA_EPI_STORE && PA_NT_STORE_MAXN > 0 && a.N > PA_NT_STORE_MAXN) {       // uniform
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, ors, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, ors, off + ldb, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, o ? ors2 : ors, off, 0, PA_AUX_ST_OUT);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, o ? ors2 : ors, off + ldb, 0, PA_AUX_ST_OUT);
+                }
             }
     }
     if constexpr (EPI == PA_EPI_DGELU) {
@@ -608,7 +685,7 @@ __device__ __forceinline__ void gemm_epilogue_v2_resid(const pa_gemm_args& a, f3
             if (hp + DEPTH < NH) aux.load_half(hp % DEPTH, hp + DEPTH);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[it]), ors, vo + (uint32_t)(hp * 16 + it * 4) * ldo4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[it]), ors, vo + (uint32_t)(hp * 16 + it * 4) * ldo4, 0, PA_AUX_ST_RES);
         }
     }
 }
@@ -1150,10 +1227,17 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
     auto dmaA = [&](int slot, int step) {
         char* sA = smem + G::a_off(slot) + wave * (A_PER * 1024);
         const char* sb = baseA + (int64_t)step * KB;
+        if (EPI == PA_EPI_STORE && PA_NT_A_STORE_MAXN > 0 && a.N <= PA_NT_A_STORE_MAXN) {       // uniform
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffA[i]),
+                                                 (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 2);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffA[i]),
-                                             (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sA + i * 1024), 16, 0, EPI == PA_EPI_RESID ? PA_AUX_DMA_A_RESID : PA_AUX_DMA_A);
     };
     auto dmaB = [&](int slot, int step) {
         char* sB = smem + G::b_off(slot) + wave * 4096;
@@ -1161,7 +1245,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(const pa_gemm_args
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voffB[i]),
-                                             (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sB + i * 1024), 16, 0, PA_AUX_DMA_B);
     };
 
     const int rsw = swz_f128(lane);
@@ -1750,14 +1834,21 @@ __device__ __forceinline__ void gemm_tn_stagger_range(const pa_gemm_args& a, con
     }
     const char* baseA = (const char*)a.A + (int64_t)st_begin * MROWS * a.lda * 2;
     const char* baseB = (const char*)a.B + (int64_t)st_begin * MROWS * a.ldb * 2;
-    auto dma = [&](const char* base, int ld, const uint32_t (&voff)[PER], char* dst, int step) {
+    auto dma = [&](const bool opB, const char* base, int ld, const uint32_t (&voff)[PER], char* dst, int step) __attribute__((always_inline)) {
         const char* sb = base + (int64_t)step * MROWS * ld * 2;              // uniform
         const int valid = Mtok - (st_begin + step) * MROWS;                  // token rows that exist in this stage
         if (valid >= MROWS) {
+            if (opB) {         // (a constant at both call sites: folded after inlining)
 #pragma unroll
-            for (int i = 0; i < PER; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                for (int i = 0; i < PER; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, PA_AUX_DMA_TN_B);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, PA_AUX_DMA_TN_A);
+            }
         } else {   // last stage of the last split: rows past the end re-read the last token (zeroed by zero_tail)
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -1767,8 +1858,8 @@ __device__ __forceinline__ void gemm_tn_stagger_range(const pa_gemm_args& a, con
             }
         }
     };
-    auto dmaA = [&](int buf, int step) { dma(baseA, a.lda, voffA, smem + buf * STAGE_BYTES + wave * (PER * 1024), step); };
-    auto dmaB = [&](int buf, int step) { dma(baseB, a.ldb, voffB, smem + buf * STAGE_BYTES + OP_BYTES + wave * (PER * 1024), step); };
+    auto dmaA = [&](int buf, int step) { dma(false, baseA, a.lda, voffA, smem + buf * STAGE_BYTES + wave * (PER * 1024), step); };
+    auto dmaB = [&](int buf, int step) { dma(true, baseB, a.ldb, voffB, smem + buf * STAGE_BYTES + OP_BYTES + wave * (PER * 1024), step); };
     // token rows beyond Mtok (last stage only) were filled from a clamped row: zero what THIS wave staged,
     // after its DMA landed and before the barrier that publishes the stage
     auto zero_tail = [&](int buf, int step) {
@@ -2728,7 +2819,13 @@ __global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const Redu
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t0; i < n4; i += stride) {
         f32x4 s = d.accumulate ? ((const f32x4*)d.out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < d.splits; ++z) s += *(const f32x4*)(d.partial + (int64_t)z * n + i * 4);
+        for (int z = 0; z < d.splits; ++z) {
+#if PA_NT_LD_SLAB
+            s += __builtin_nontemporal_load((const f32x4*)(d.partial + (int64_t)z * n + i * 4));
+#else
+            s += *(const f32x4*)(d.partial + (int64_t)z * n + i * 4);
+#endif
+        }
         ((f32x4*)d.out)[i] = s;
     }
     for (int64_t i = n4 * 4 + t0; i < n; i += stride) {

@@ -12,16 +12,49 @@ namespace pa {
 static constexpr int LN_MAXV = 8;       // float4 per lane -> D <= 2048 (kernels are instantiated for 1,2,3,4,8)
 static constexpr int LN_BWD_BLOCKS = 1024;
 
+// Cache policy (A/B build knobs, round 6 sweep profiles/r06_cache_policy.txt): PA_LN_NT_LD = the row operands that are read for
+// the last time here (x in the forward; dy, x, dres in the backward) as non-temporal loads, PA_LN_NT_ST bit 0 = the f32 outputs
+// (dx), bit 1 = the low-precision outputs (y, dx_lp: the next GEMM's A operand) as non-temporal stores
+#ifndef PA_LN_NT_LD
+#define PA_LN_NT_LD 0
+#endif
+#ifndef PA_LN_NT_ST
+#define PA_LN_NT_ST 0
+#endif
+__device__ __forceinline__ float4 ldrow4(const float* p) {
+#if PA_LN_NT_LD
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load((const f4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const float4*)p;
+#endif
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float4& v);
-template <> __device__ __forceinline__ void store4<float>(float* p, const float4& v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store4<float>(float* p, const float4& v) {
+#if PA_LN_NT_ST & 2
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, (f4*)p);
+#else
+    *(float4*)p = v;
+#endif
+}
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float4& v) {
     bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+#if PA_LN_NT_ST & 2
+    __builtin_nontemporal_store(o, (bf16x4*)p);
+#else
     *(bf16x4*)p = o;
+#endif
 }
 template <typename T> __device__ __forceinline__ float4 load4(const T* p);
-template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return ldrow4(p); }
 template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
+#if PA_LN_NT_LD
+    const bf16x4 v = __builtin_nontemporal_load((const bf16x4*)p);
+#else
     const bf16x4 v = *(const bf16x4*)p;
+#endif
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
@@ -40,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) { v[i] = *(const float4*)(xr + 4 * c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        if (c < nv) { v[i] = ldrow4(xr + 4 * c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
     }
     const float mu = wave_sum(s) / (float)D;
     float s2 = 0.f;
@@ -102,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                const float4 xv = *(const float4*)(x + base + 4 * c);
+                const float4 xv = ldrow4(x + base + 4 * c);
                 const float4 d = load4<T>(dy + base + 4 * c);
                 xh[i] = make_float4((xv.x - mu) * r, (xv.y - mu) * r, (xv.z - mu) * r, (xv.w - mu) * r);
                 gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
@@ -121,10 +154,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 o.x = r * (gy[i].x - c1 - xh[i].x * c2); o.y = r * (gy[i].y - c1 - xh[i].y * c2);
                 o.z = r * (gy[i].z - c1 - xh[i].z * c2); o.w = r * (gy[i].w - c1 - xh[i].w * c2);
                 if (dres) {
-                    const float4 dr = *(const float4*)(dres + base + 4 * c);
+                    const float4 dr = ldrow4(dres + base + 4 * c);
                     o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
                 }
-                *(float4*)(dx + base + 4 * c) = o;
+                {
+#if PA_LN_NT_ST & 1
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f4{o.x, o.y, o.z, o.w}, (f4*)(dx + base + 4 * c));
+#else
+                    *(float4*)(dx + base + 4 * c) = o;
+#endif
+                }
                 if (dx_lp) store4<T>(dx_lp + base + 4 * c, o);
                 ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
             }

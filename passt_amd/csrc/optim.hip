@@ -92,6 +92,36 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
 // transposed cast), everything else in runs of 4096 elements.  Same adamw_one() as adamw_kernel: parameters, moments and both
 // copies are bit-identical to adamw_kernel + stage_weights_kernel (tests/test_gpu_model.py).
 struct AdamwHyper { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; };
+// Cache policy of the matrix path (A/B build knob, round 6 sweep profiles/r06_cache_policy.txt): bit 0 = parameters, moments and
+// gradients (each touched once per step) as non-temporal loads / stores, bit 1 = the GEMM-ready copies as non-temporal stores
+#ifndef PA_OPT_NT
+#ifdef PA_NO_CACHE_POLICY
+#define PA_OPT_NT 0
+#else
+#define PA_OPT_NT 1        // (with the slab loads of the finishing reduction: -0.2 % of the step; the copies: +- 0)
+#endif
+#endif
+template <typename V> __device__ __forceinline__ V opt_ld(const V* p) {
+#if PA_OPT_NT & 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void opt_st(V* p, const V& v) {
+#if PA_OPT_NT & 1
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename V> __device__ __forceinline__ void opt_st_copy(V* p, const V& v) {
+#if PA_OPT_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 template <typename TO>
 __global__ __launch_bounds__(256) void adamw_stage_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -158,7 +188,7 @@ __global__ __launch_bounds__(256) void adamw_stage_kernel(float* __restrict__ p,
             const int r = r0 + lr + 16 * i, c = c0 + l4;
             in[i] = r < d.rows && c < d.cols;
             const int64_t at = in[i] ? (int64_t)r * d.cols + c : 0;
-            pv[i] = *(const f32x4*)(pp + at); mv[i] = *(const f32x4*)(mp + at); vv[i] = *(const f32x4*)(vp + at); gv[i] = *(const f32x4*)(gp + at);
+            pv[i] = opt_ld((const f32x4*)(pp + at)); mv[i] = opt_ld((const f32x4*)(mp + at)); vv[i] = opt_ld((const f32x4*)(vp + at)); gv[i] = opt_ld((const f32x4*)(gp + at));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -171,9 +201,9 @@ __global__ __launch_bounds__(256) void adamw_stage_kernel(float* __restrict__ p,
                     adamw_one(pe, gv[i][e], me, ve, h.lr, h.b1, h.b2, h.eps, h.wd, h.bc1, h.bc2_sqrt);
                     pv[i][e] = pe; mv[i][e] = me; vv[i][e] = ve;
                 }
-                *(f32x4*)(pp + at) = pv[i]; *(f32x4*)(mp + at) = mv[i]; *(f32x4*)(vp + at) = vv[i];
+                opt_st((f32x4*)(pp + at), pv[i]); opt_st((f32x4*)(mp + at), mv[i]); opt_st((f32x4*)(vp + at), vv[i]);
                 if (dst) {
-                    if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst + at) = bf16x4{(bf16)pv[i][0], (bf16)pv[i][1], (bf16)pv[i][2], (bf16)pv[i][3]};
+                    if constexpr (sizeof(TO) == 2) opt_st_copy((bf16x4*)(dst + at), bf16x4{(bf16)pv[i][0], (bf16)pv[i][1], (bf16)pv[i][2], (bf16)pv[i][3]});
                     else *(f32x4*)(dst + at) = pv[i];
                 }
             } else {
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(256) void adamw_stage_kernel(float* __restrict__ p,
             const int c = c0 + lr + 16 * i, r = r0 + l4;
             if (c < d.cols && r < d.rows) {
                 const f32x4 w = {tile[l4][lr + 16 * i], tile[l4 + 1][lr + 16 * i], tile[l4 + 2][lr + 16 * i], tile[l4 + 3][lr + 16 * i]};
-                if constexpr (sizeof(TO) == 2) *(bf16x4*)(dst_t + (int64_t)c * d.rows + r) = bf16x4{(bf16)w[0], (bf16)w[1], (bf16)w[2], (bf16)w[3]};
+                if constexpr (sizeof(TO) == 2) opt_st_copy((bf16x4*)(dst_t + (int64_t)c * d.rows + r), bf16x4{(bf16)w[0], (bf16)w[1], (bf16)w[2], (bf16)w[3]});
                 else *(f32x4*)(dst_t + (int64_t)c * d.rows + r) = w;
             }
         }
