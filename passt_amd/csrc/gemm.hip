@@ -55,19 +55,20 @@ static constexpr int PROBE_SLOTS = 512;
 #endif
 
 // ---- Cache policy of the step's GEMM memory instructions, per role (round 6, profiles/r06_cache_policy.txt) ----------------
-// The `aux` immediate of the buffer / LDS-DMA instructions: 1 = sc0, 2 = nt (non-temporal), 16 = sc1.  An XCD's L2 is 4 MiB;
-// the weights of one GEMM are 1.2 - 4.7 MB and are re-read by every row band, the activation tiles by N / 256 column tiles,
-// while every output line and every epilogue operand row is touched exactly once.  With the default policy those single-use
-// lines push the re-used ones out of the L2 (and the 256 MiB Infinity Cache): marking them non-temporal is worth 1.5 - 2.4 % of
-// the whole training step (config #2, five boxes, ABBA order: 22.39 -> 21.98, 21.78 -> 21.46, 21.73 -> 21.27 ms), e.g. the fc2
-// + residual GEMM 106 -> 97 us, fc1 + GELU 171 -> 160 us.  What the sweep settled, role by role:
+// The `aux` immediate of the buffer / LDS-DMA instructions: 1 = sc0, 2 = nt (non-temporal), 16 = sc1.  Every output line and
+// every epilogue operand row of a GEMM is touched exactly once by that GEMM; weights are re-read by every row band, activation
+// tiles by N / 256 column tiles, and the NEXT kernel wants this kernel's outputs.  With the default policy the single-use
+// lines compete for the caches with the re-used ones; marked non-temporal they do not: 1.5 - 2.4 % of the whole training step
+// (config #2, same box, ABBA: 22.39 -> 21.98, 21.78 -> 21.46, 21.98 -> 21.48 ms; ESC-50 - 2.9 %, config #4 - 1.6 %), e.g.
+// fc2 / proj + residual 104.5 -> 95.0 us, fc1 + GELU 170 -> 157 us.  The bytes crossing the L2's fabric side do NOT change
+// (FETCH_SIZE / WRITE_SIZE: 439 against 440 MB per launch): the effect is behind them, in the 256 MiB Infinity Cache / HBM.
+// What the sweep settled, role by role:
 //   nt  fc1's blocked pre-activation (written in the forward, next read in the backward)                      PA_AUX_ST_PRE
 //   nt  the bf16 outputs of the STORE / GELU / GELU' epilogues (full 128-byte lines per 8 lanes)               PA_AUX_ST_OUT
 //   nt  the epilogue operand rows read once (residual rows, pre-activation blocks)                            PA_AUX_LD_AUX
-//   nt  the A operand of the residual GEMMs (N = D: a tile is read by D / 256 column tiles only, and fc2's
-//       W^T alone is 4.7 MB)                                                                                  PA_AUX_DMA_A_RESID
+//   nt  the A operand of the residual GEMMs (N = D: a tile is read by D / 256 column tiles only)              PA_AUX_DMA_A_RESID
 //   nt  the split-K slabs when the finishing reduction reads them (each once)                                 PA_NT_LD_SLAB
-//   default: the f32 residual-stream output (nt: the LayerNorm behind it reads HBM, +0.5 %), the A operand of every other GEMM
+//   default: the f32 residual-stream output (nt: the LayerNorm behind it slows down, +0.5 %), the A operand of every other GEMM
 //       (nt: fc1 + GELU 170 -> 188 us), the weights (nt: +4 % on the step), the weight-gradient operands and slab stores
 //       (+- 0), sc1 instead of nt on the outputs (half the gain), nt on the A operand of plain-store GEMMs with N = D (+0.5 %).
 // -DPA_NO_CACHE_POLICY builds the library with the default policy everywhere (A/B: tools/build_variant.sh).
