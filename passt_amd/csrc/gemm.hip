@@ -83,6 +83,15 @@ static constexpr int PROBE_SLOTS = 512;
 #ifndef PA_AUX_ST_OUT
 #define PA_AUX_ST_OUT PA_CP(2)
 #endif
+#ifndef PA_AUX_ST_ACT
+#define PA_AUX_ST_ACT PA_AUX_ST_OUT      // ... fc1's activation only (the fc2 GEMM behind it reads it non-temporally)
+#endif
+#ifndef PA_AUX_ST_DPRE
+#define PA_AUX_ST_DPRE PA_AUX_ST_OUT     // ... the GELU' epilogue's output only
+#endif
+#ifndef PA_AUX_ST_STORE
+#define PA_AUX_ST_STORE PA_AUX_ST_OUT    // ... the plain-store epilogue only
+#endif
 #ifndef PA_AUX_ST_RES
 #define PA_AUX_ST_RES 0
 #endif
@@ -631,8 +640,9 @@ __device__ __forceinline__ void gemm_epilogue_v2_bf16(const pa_gemm_args& a, f32
                     __builtin_amdgcn_raw_buffer_store_b128(lo, ors, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(hi, ors, off + ldb, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(lo, o ? ors2 : ors, off, 0, PA_AUX_ST_OUT);
-                    __builtin_amdgcn_raw_buffer_store_b128(hi, o ? ors2 : ors, off + ldb, 0, PA_AUX_ST_OUT);
+                    constexpr int AUX_ST = EPI == PA_EPI_GELU ? PA_AUX_ST_ACT : (EPI == PA_EPI_DGELU ? PA_AUX_ST_DPRE : PA_AUX_ST_STORE);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, o ? ors2 : ors, off, 0, AUX_ST);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, o ? ors2 : ors, off + ldb, 0, AUX_ST);
                 }
             }
     }

@@ -313,6 +313,45 @@ def test_attention_isa_never_touches_in_flight_lds_fragments():
     assert r.returncode == 0, r.stdout[-2000:]
 
 
+def test_shipped_library_carries_the_cache_policy():
+    """Round 6 (profiles/r06_cache_policy.txt): the step's GEMMs mark what they touch once non-temporal -- outputs, epilogue
+    operand rows, the A operand of the residual GEMMs -- and nothing else (weights and the other A operands stay on the default policy;
+    attention and LayerNorm kernels carry no hint: both measured slower with one).  Checked on the ISA of the BUILT library
+    (tools/so_isa.py disassembles the code objects embedded in libpasst_amd.so): a build with -DPA_NO_CACHE_POLICY, or a lost `aux`
+    operand, would go unnoticed by every numerical test."""
+    import importlib.util
+    from passt_amd import _lib
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("no llvm-objdump / library not built")
+    spec = importlib.util.spec_from_file_location("so_isa", os.path.join(ROOT, "tools", "so_isa.py"))
+    so_isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(so_isa)
+    cos = so_isa.code_objects(_lib.LIB_PATH)
+    by_kernel = {}
+    for _, text in cos:
+        by_kernel.update(so_isa.kernel_bodies(text))
+
+    def counts(fragment):
+        hits = [k for k in by_kernel if fragment in k]
+        assert len(hits) == 1, (fragment, hits)
+        body = by_kernel[hits[0]]
+        c = so_isa.policy_counts(body)
+        c["lds_dma"] = body.count("global_load_lds_dwordx4")
+        return c
+    # <bf16, EPI, TM, A3, BLK, TR>: the kernels config #2 runs (pick_nt_variant): store / residual TM 3 with A two tiles ahead, MLP TM 4 blocked
+    store, gelu = counts("gemm_nt_stagger_kernelIDF16bLi0ELi3ELb1ELb0ELb0E"), counts("gemm_nt_stagger_kernelIDF16bLi1ELi4ELb0ELb1ELb0E")
+    resid, dgelu = counts("gemm_nt_stagger_kernelIDF16bLi2ELi3ELb1ELb0ELb0E"), counts("gemm_nt_stagger_kernelIDF16bLi3ELi4ELb0ELb1ELb0E")
+    assert store["buffer_store nt"] >= 8 and store["lds_dma nt"] == 0
+    assert gelu["buffer_store nt"] >= 16 and gelu["lds_dma nt"] == 0                  # activation + blocked pre-activation
+    assert resid["buffer_load nt"] >= 8 and resid["buffer_store nt"] == 0             # residual rows in; the f32 stream out stays cached
+    assert 0 < resid["lds_dma nt"] < resid["lds_dma"]                                 # A non-temporal, the weights not
+    assert dgelu["buffer_store nt"] >= 8 and dgelu["buffer_load nt"] >= 8 and dgelu["lds_dma nt"] == 0
+    assert counts("adamw_stage_kernelIDF16b")["global nt"] > 0
+    for frag in ("attn_fwd_kernelIDF16bLb1E", "attn_bwd_fused_kernelILb0E", "ln_fwd_kernelIDF16bLi3E", "ln_bwd_kernelIDF16bLi3E", "gemm_tn_stagger_batched_kernel"):
+        c = counts(frag)
+        assert c["buffer_store nt"] == c["buffer_load nt"] == c["lds_dma nt"] == c["global nt"] == 0, (frag, c)
+
+
 def test_single_pass_attention_backward_index_math_on_the_cpu():
     """tools/emulate_attn_bwd_fused.py: the transposition buffer T of attn_bwd_fused_kernel (phase-1 write addresses, XOR swizzle)
     and the phase-2 operand fetches (ds_read_b64_tr_b16 piece addresses for K^T and dS^T, 16x16x32 MFMA k-slot order) reproduce
