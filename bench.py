@@ -760,7 +760,9 @@ def run(args):
                                     + (", passt_amd.ddp.attach(net)" if world > 1 else "")),
                            "gemm_launch": ("one work item per workgroup (PA_GEMM_NO_PERSIST: the all-reduce kernels share the CUs)"
                                            if getattr(net, "_gemm_flags", 0) & ops._lib.GEMM_NO_PERSIST else "persistent, 256 workgroups"),
-                           "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM"},
+                           "input": f"spectrogram (B,1,128,{frames})" if args.no_mel else f"waveform (B,1,{cfgd['clip']}) f32 resident in HBM",
+                       "cache_policy": "non-temporal by role in the GEMM / optimizer kernels (DESIGN 4.1, profiles/r06_cache_policy.txt); "
+                                       "a library built with -DPA_NO_CACHE_POLICY runs the default policy"},
                 "algorithmic_gflop_per_clip": round(gflop_clip, 2),
                 "mfma_frac_end_to_end": round(value / world * gflop_clip / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
                 # the same on the FLOPs actually executed: the prefix-only tail skips part of the last block (exactly)
