@@ -212,6 +212,10 @@ typedef struct {
 int pa_gemm_blocked_pre_ok(int M, int N, int K);
 int64_t pa_gemm_blocked_pre_elems(int M, int N);
 int64_t pa_gemm_colsum_ws_floats(int M, int N);
+/* Memory policy (round 6, csrc/gemm.hip PA_AUX_*): the bf16 outputs (out_lp, out_lp2), the blocked pre-activation and the epilogue
+ * operand rows (resid, aux) of the bf16 role-split kernels are written / read NON-TEMPORALLY, as is the A operand of PA_EPI_RESID
+ * calls: they are complete and visible at the end of the launch like any other result; a consumer simply finds them in HBM rather
+ * than in the Infinity Cache.  A library built with -DPA_NO_CACHE_POLICY uses the default policy everywhere (same results). */
 int pa_gemm_nt(const pa_gemm_args* a, void* stream);
 /* The same product for problems too small to fill the chip (few output tiles, long K: the [M][768] outputs of fc2 / the
  * fc1 and qkv input gradients at ESC-50 batch sizes, ex_esc50.py:40; the prefix-only tail of the last block): K is cut into
